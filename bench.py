@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native BNN-PYNQ runtime.
+
+Metric (BASELINE.json): images/sec (whole node), CNV-W1A1 on CIFAR-10-shaped
+(32x32x3 uint8) batches.  A "step" is one pass of the hot path (all nine stages
+of cnvW1A1, image bytes in HBM -> class index in HBM) over one batch of
+synthetic images per GPU.  Work per GPU is fixed as N grows ("weak" scaling);
+images are independent, so ranks exchange nothing on the data path: the only
+collective is the one-time RCCL broadcast of the packed parameter blob.
+
+    python bench.py                          # 1 GPU, defaults finish in ~1-2 min
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Everything the timed region runs goes through the product's C ABI
+(include/bnn_mi355x.h).  oracle/ is touched only by the cpu_baseline leg (rank
+0, N=1): the CPU restatement timed on this host's cores on a bounded sample,
+which doubles as a parity check of the GPU classes on that sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch  # before the product library: one HIP runtime per process
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import gpu_lib as gl  # noqa: E402  (ctypes binding of the product C ABI)
+
+# algorithmic bytes per image of the fused path: 3072 in + 4 out
+ALG_BYTES = {"cnv": 3072 + 4, "lfc": 784 + 4}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_TOPS = 78.64         # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, one 32-bit lane-op each
+# VALU lane-ops per image: 4 per 64-bit XNOR-popcount word (2 v_xor + 2 v_bcnt), 905 216 words;
+# layer 0: 900 px x 64 ch x 9 v_dot4
+VALU_OPS = {"cnvW1A1": 905216 * 4 + 900 * 64 * 9, "lfcW1A1": 47104 * 4}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=131072, help="images per GPU per step")
+    ap.add_argument("--network", default="cnvW1A1")
+    ap.add_argument("--dataset", default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target length of the CPU baseline leg")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % a.gpus)
+        a.gpus = world
+    is_cnv = a.network.startswith("cnv")
+    dataset = a.dataset or ("cifar10" if is_cnv else "mnist")
+    ncls = 10
+    isz = 3072 if is_cnv else 784
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    L = gl.load(a.network)
+    assert L.bnn_mi355x_set_device(local_rank) == 0
+
+    # ---- parameters: rank 0 packs the reference's param files, everyone else gets the blob over RCCL
+    pdir = gl.param_dir(dataset, a.network)
+    if world == 1:
+        L.load_parameters(pdir.encode())
+        err = L.bnn_mi355x_last_error().decode()
+        if err:
+            sys.exit(err)
+    else:
+        if rank == 0:
+            blob = torch.from_numpy(gl.pack_params(a.network, pdir))
+            size = torch.tensor([blob.numel()], dtype=torch.int64, device=dev)
+        else:
+            size = torch.zeros(1, dtype=torch.int64, device=dev)
+        dist.broadcast(size, 0)
+        d_blob = blob.to(dev) if rank == 0 else torch.empty(int(size.item()), dtype=torch.uint8, device=dev)
+        dist.broadcast(d_blob, 0)  # the one collective of the whole job (xGMI, ~210 KB)
+        host = d_blob.cpu().numpy()
+        if L.bnn_mi355x_import_params(host.ctypes.data, host.size) != 0:
+            sys.exit(L.bnn_mi355x_last_error().decode())
+
+    # ---- synthetic batch, resident in HBM before the timed region starts
+    g = torch.Generator(device=dev)
+    g.manual_seed(1 + rank)
+    imgs = torch.randint(0, 256, (a.batch, isz), dtype=torch.uint8, device=dev, generator=g)
+    classes = torch.zeros(a.batch, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream()
+    assert L.bnn_mi355x_reserve(a.batch) == 0
+
+    def step():
+        rc = L.bnn_mi355x_inference_device(imgs.data_ptr(), a.batch, ncls, classes.data_ptr(), None, None,
+                                           stream.cuda_stream)
+        if rc != 0:
+            raise RuntimeError(L.bnn_mi355x_last_error().decode())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    L.bnn_mi355x_profile(1)  # HIP events around every stage, on the stream the kernels run on
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stage_ms = (C.c_float * 16)()
+    nchunks = C.c_int(0)
+    nst = L.bnn_mi355x_profile_read(stage_ms, 16, C.byref(nchunks))
+    L.bnn_mi355x_profile(0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    total_images = a.batch * a.steps * world
+    value = total_images / elapsed
+    # ---- roofline: whole fused path priced at its algorithmic bytes, over the device time of all stages
+    launches = max(nchunks.value, 1)
+    per_stage = [stage_ms[i] / a.steps for i in range(nst)]          # ms per step (all chunks of a step)
+    imgs_per_launch = a.batch * a.steps / launches
+    names = [L.bnn_mi355x_stage_name(i).decode() for i in range(nst)]
+    dom = int(np.argmax(per_stage))
+    dev_ms = sum(per_stage)
+    alg = ALG_BYTES["cnv" if is_cnv else "lfc"]
+    achieved = alg * a.batch / (dev_ms * 1e-3) / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get(a.network, {}).get("hbm_bytes_per_step")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                "kernel": "all %d stages of one batch (dominant: %s, %.1f%% of device time)" % (
+                    nst, names[dom], 100.0 * per_stage[dom] / dev_ms),
+                "algorithmic_bytes_per_image": alg, "images_per_launch": int(imgs_per_launch),
+                "device_ms_per_step": round(dev_ms, 4),
+                "stages_ms": {names[i]: round(per_stage[i], 4) for i in range(nst)}}
+    out = {"metric": "images/sec (whole node) CNV-W1A1 CIFAR-10-shape batch" if a.network == "cnvW1A1"
+           else "images/sec (whole node) %s batch" % a.network,
+           "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+           "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "u1 (1-bit XNOR-popcount, int8 first layer)", "data": "synthetic",
+           "config": {"workload": "%s, %d synthetic %s images per GPU per step, inputs resident in HBM, params %s/%s"
+                      % (a.network, a.batch, "32x32x3 uint8" if is_cnv else "28x28 uint8", dataset, a.network),
+                      "images_per_gpu_per_step": a.batch, "parallelism": "dp%d (batch shards, no data-path collective)" % world},
+           "roofline": roofline}
+    if a.network in VALU_OPS:
+        tops = VALU_OPS[a.network] * a.batch / (dev_ms * 1e-3) / 1e12
+        out["valu"] = {"lane_ops_per_image": VALU_OPS[a.network], "achieved": round(tops, 3), "peak": VALU_PEAK_TOPS,
+                       "unit": "T lane-op/s", "frac": round(tops / VALU_PEAK_TOPS, 4),
+                       "note": "the path is integer-VALU bound (v_xor + v_bcnt), not HBM bound: this is the meaningful ceiling"}
+
+    # ---- CPU baseline: the CPU restatement on this host's cores, bounded sample, same images
+    if world == 1 and not a.no_cpu_baseline:
+        import oracle_lib as ol
+        o = ol.Oracle(a.network, ol.param_dir(dataset, a.network))
+        host = imgs[: min(a.batch, 65536)].cpu().numpy()
+        cores = os.cpu_count() or 1
+        probe = min(256, host.shape[0])
+        run = (lambda x: o.scores_fast(x, cores)) if is_cnv else (lambda x: o.words_fast(x, cores))
+        t1 = time.perf_counter()
+        run(host[:probe])
+        rate = probe / (time.perf_counter() - t1)
+        sample = int(max(probe, min(host.shape[0], rate * a.cpu_seconds)))
+        t1 = time.perf_counter()
+        run(host[:sample])                       # the timed CPU leg: compute only, like the GPU's timed region
+        dt = time.perf_counter() - t1
+        ref = o.classes_batched(host[:sample], ncls, cores)
+        got = classes[:sample].cpu().numpy()
+        if not (got == ref).all():
+            sys.exit("PARITY FAILURE: GPU classes differ from the CPU restatement on the baseline sample")
+        out["cpu_baseline"] = {"value": round(sample / dt, 1), "unit": "images/s", "cores": cores, "kind": "port",
+                               "sample": "first %d images of the GPU batch, %.1f s, popcount+OpenMP restatement "
+                                         "(oracle/), classes equal to the GPU's on all of them" % (sample, dt)}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

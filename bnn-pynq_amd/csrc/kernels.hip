@@ -1,0 +1,505 @@
+// kernels.hip -- CDNA4 (gfx950) kernels of the FINN QNN hot path.
+//
+// What they replace (all of it un-vendored finn-hlslib code instantiated from
+// bnn/src/network/<net>/hw/top.cpp:210-236):
+//   ConvolutionInputGenerator (SWU / im2col)            -> the window gather at the top of each conv kernel
+//   Matrix_Vector_Activate_Batch (MVAU)                 -> the per-neuron XNOR/AND + popcount loops
+//   ThresholdsActivation::activate                      -> the compare against the row's thresholds
+//   StreamingMaxPool_Batch / _Precision_Batch           -> min/max over the 2x2 quad before the compare
+//   StreamingDataWidthConverter / Mem2Stream / Stream2Mem -> nothing: activations stay bit-packed HWC words in HBM
+//
+// Execution model (why it looks like this on MI355X):
+//   * One LANE owns one work item (an output pixel, a 2x2 quad of output
+//     pixels, or an image) and keeps that item's input window in VGPRs for the
+//     whole kernel: activations are read from HBM/L2 exactly once per stage.
+//   * All 64 lanes of a wave (and all 4 waves of a block) work on the SAME 32
+//     output neurons (blockIdx.y selects the group).  The weight row of the
+//     neuron being evaluated is therefore wave-uniform: it is fetched with
+//     wide SCALAR loads (s_load_dwordx8/x16 through the constant address
+//     space) and used directly as the SGPR operand of v_xor_b32 / v_and_b32 /
+//     v_dot4c_i32_i8.  Weights cost no VGPRs, no LDS traffic and no vector
+//     memory instructions; the VALU does nothing but xor + v_bcnt (which folds
+//     the accumulate).  That is 4 VALU ops per 64-bit word of 1-bit MACs.
+//   * The 32 results of a lane are assembled into one 32-bit word in a VGPR and
+//     stored once: outputs are already in the bit-packed layout the next stage
+//     reads.  Max-pool is a min/max over the quad's 4 accumulators before the
+//     threshold compare (thresholding is monotone), so it is free.
+//   * No MFMA: the path is bitwise.  No LDS: there is no data shared between
+//     lanes that the scalar path does not already broadcast for free.
+//
+// Data layout in HBM: see DESIGN.md ("Data layout").
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace bnn {
+namespace {
+
+// scalar (constant) address space: uniform loads through it become s_load_*
+typedef const uint32_t __attribute__((address_space(4))) *kptr32;
+typedef const uint64_t __attribute__((address_space(4))) *kptr64;
+
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ int pc64(uint64_t x) { return __builtin_popcountll(x); }
+
+// ---------------------------------------------------------------------------
+// activation outputs
+// ---------------------------------------------------------------------------
+// 1-bit maps:  [pixel][Cout/32] dwords, bit c of dword g = channel 32g+c fired (+1).
+// 2-bit maps:  [pixel][Cout/64][plane] u64, plane 0 = sign (1 <=> -1), plane 1 = non-zero.
+template <bool OUT2>
+__device__ __forceinline__ void store_bits(uint32_t *__restrict__ out, size_t pix, int groups, int g,
+                                           uint32_t b0, uint32_t b1) {
+  if constexpr (!OUT2) {
+    out[pix * groups + g] = b0;
+  } else {
+    const size_t w64 = pix * (groups >> 1) + (g >> 1);
+    out[(w64 * 2 + 0) * 2 + (g & 1)] = b0;
+    out[(w64 * 2 + 1) * 2 + (g & 1)] = b1;
+  }
+}
+
+// fire0/fire1 = (T0 < acc), (T1 < acc).  1-bit: bit = fire0.
+// 2-bit: value = -1 + fire0 + fire1 -> sign = !(f0|f1), non-zero = (f0 == f1)
+template <bool OUT2>
+__device__ __forceinline__ void push_bits(uint32_t &b0, uint32_t &b1, bool f0, bool f1, uint32_t bit) {
+  if constexpr (!OUT2) {
+    b0 |= f0 ? bit : 0u;
+  } else {
+    b0 |= (!f0 && !f1) ? bit : 0u;
+    b1 |= (f0 == f1) ? bit : 0u;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// one neuron x one window: the MVAU inner product on bit-packed words
+// ---------------------------------------------------------------------------
+// ARITH        per 64 synapses                                   acc / compare
+// AR_XNOR      m += popc(w ^ a)                                  fire = m < t
+// AR_TB        m += popc(za & (sa ^ w))                          fire = T < nz - 2m   (nz = popc(za) summed once per window)
+// AR_TT        z += popc(za & zw); m += popc(za & zw & (sa^sw))  fire = T < z - 2m
+template <int ARITH>
+__device__ __forceinline__ void mac(int &m, int &z, uint64_t as, uint64_t az, kptr64 w) {
+  if constexpr (ARITH == AR_XNOR) {
+    m += pc64(w[0] ^ as);
+  } else if constexpr (ARITH == AR_TB) {
+    m += pc64(az & (as ^ w[0]));
+  } else {
+    const uint64_t zz = az & w[1];
+    z += pc64(zz);
+    m += pc64(zz & (as ^ w[0]));
+  }
+}
+
+template <int ARITH>
+constexpr int planes_in() { return ARITH == AR_XNOR ? 1 : 2; }
+template <int ARITH>
+constexpr int wplanes() { return ARITH == AR_TT ? 2 : 1; }
+
+// turns (m, z, nz_total) into the quantity compared with the thresholds.
+// XNOR family: smaller is "more positive" -> we compare m < t, so for pooling
+// take the MIN over the quad; ternary family: acc, take the MAX.
+template <int ARITH>
+__device__ __forceinline__ int finish(int m, int z, int nzt) {
+  if constexpr (ARITH == AR_XNOR) return m;
+  else if constexpr (ARITH == AR_TB) return nzt - 2 * m;
+  else return z - 2 * m;
+}
+template <int ARITH>
+__device__ __forceinline__ bool fires(int v, int t) {
+  if constexpr (ARITH == AR_XNOR) return v < t;
+  else return t < v;
+}
+template <int ARITH>
+__device__ __forceinline__ int pool2(int a, int b) {
+  if constexpr (ARITH == AR_XNOR) return a < b ? a : b;
+  else return a > b ? a : b;
+}
+
+// ---------------------------------------------------------------------------
+// Stage 0 of the CNV nets: 32x32x3 uint8 (planar CHW, as in a CIFAR-10 record)
+// -> 30x30x64 thresholded map.
+// Replaces: chaninterleave + quantiseAndPack<8,1> (foldedmv-offload.h:129-144,
+// 381-386), the 64->192->24 width converters and ConvLayer_Batch<L0..>
+// (top.cpp:210-214).  One lane = one output pixel; the 27 int8 taps live in 9
+// dwords (3 taps of one (channel,row) + one don't-care byte whose weight byte
+// is 0) and each neuron costs 9 v_dot4c_i32_i8 against SGPR weight dwords.
+// ---------------------------------------------------------------------------
+// uint8 p -> int8 q = clamp(floor(256*p/255 - 128 + 0.5)) = p - 128 + (p >= 128) - (p == 255),
+// four bytes at a time (no carry can cross a byte: see DESIGN.md).
+__device__ __forceinline__ uint32_t quantise4(uint32_t p) {
+  const uint32_t t = p ^ 0x80808080u;                         // p - 128 per byte
+  const uint32_t hi = (p >> 7) & 0x01010101u;                 // p >= 128
+  const uint32_t f = (((t & 0x7F7F7F7Fu) + 0x01010101u) >> 7) & hi;  // p == 255
+  return t + (hi ^ f);
+}
+
+template <bool OUT2>
+__global__ __launch_bounds__(kBlock) void k_conv0(const uint8_t *__restrict__ imgs, uint32_t *__restrict__ out,
+                                                   const uint32_t *__restrict__ rows, int n_items) {
+  const int item = blockIdx.x * kBlock + threadIdx.x;
+  if (item >= n_items) return;
+  const int img = item / 900, p = item - img * 900;
+  const int oy = p / 30, ox = p - oy * 30;
+  const uint32_t *__restrict__ im32 = reinterpret_cast<const uint32_t *>(imgs + (size_t)img * 3072);
+  const int sh = ox & 3;
+  uint32_t a[9];
+#pragma unroll
+  for (int c = 0; c < 3; c++)
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const int idx = c * 256 + (oy + r) * 8 + (ox >> 2);
+      const uint32_t d0 = im32[idx];
+      const uint32_t d1 = im32[idx + 1 < 768 ? idx + 1 : 767];  // only ever feeds the don't-care byte when clamped
+      a[c * 3 + r] = quantise4(__builtin_amdgcn_alignbyte(d1, d0, sh));
+    }
+  kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)blockIdx.y * 32 * 12);
+  uint32_t b0 = 0, b1 = 0;
+  for (int c = 0; c < 32; c++) {
+    kptr32 r = w + c * 12;
+    int acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) acc = __builtin_amdgcn_sdot4((int)a[k], (int)r[2 + k], acc, false);
+    push_bits<OUT2>(b0, b1, (int)r[0] < acc, (int)r[1] < acc, 1u << c);
+  }
+  store_bits<OUT2>(out, (size_t)item, 2, blockIdx.y, b0, b1);
+}
+
+// ---------------------------------------------------------------------------
+// 3x3 valid conv on bit-packed maps, one lane = a 2x2 quad of output pixels
+// (4x4 input window in VGPRs), optionally followed by the 2x2 max-pool.
+// Replaces ConvolutionInputGenerator + Matrix_Vector_Activate_Batch +
+// ThresholdsActivation (+ StreamingMaxPool_Batch) for CNV layers 1, 2, 3.
+// CW = 64-bit words per pixel per plane (Cin/64), ID = input map edge.
+// Every scalar weight word feeds 4 word-MACs (the 4 pixels of the quad).
+// ---------------------------------------------------------------------------
+template <int ARITH, int CW, int ID, bool POOL, bool OUT2>
+__global__ __launch_bounds__(kBlock) void k_quad(const uint64_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                  const uint32_t *__restrict__ rows, int n_items) {
+  constexpr int OD = ID - 2, QD = OD / 2, NQ = QD * QD, PL = planes_in<ARITH>(), WPL = wplanes<ARITH>();
+  constexpr int KW = 9 * CW, ROW_DW = 2 + 2 * KW * WPL;
+  const int item = blockIdx.x * kBlock + threadIdx.x;
+  if (item >= n_items) return;
+  const int img = item / NQ, q = item - img * NQ;
+  const int qy = q / QD, qx = q - qy * QD;
+  const uint64_t *__restrict__ base = in + ((size_t)img * ID * ID + (size_t)(2 * qy) * ID + 2 * qx) * CW * PL;
+  uint64_t ws[4][4][CW], wz[4][4][PL == 2 ? CW : 1];
+#pragma unroll
+  for (int y = 0; y < 4; y++)
+#pragma unroll
+    for (int x = 0; x < 4; x++)
+#pragma unroll
+      for (int k = 0; k < CW; k++) {
+        ws[y][x][k] = base[((y * ID + x) * CW + k) * PL];
+        if constexpr (PL == 2) wz[y][x][k] = base[((y * ID + x) * CW + k) * PL + 1];
+      }
+  // AR_TB: # non-zero activations in each of the 4 windows (weight independent)
+  int nzt[2][2] = {{0, 0}, {0, 0}};
+  if constexpr (ARITH == AR_TB) {
+#pragma unroll
+    for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+      for (int dx = 0; dx < 2; dx++)
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+          for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+            for (int k = 0; k < CW; k++) nzt[dy][dx] += pc64(wz[dy + ky][dx + kx][k]);
+  }
+  kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)blockIdx.y * 32 * ROW_DW);
+  uint32_t b0[4] = {0, 0, 0, 0}, b1[4] = {0, 0, 0, 0};
+  for (int c = 0; c < 32; c++) {
+    kptr32 r = w + c * ROW_DW;
+    kptr64 rw = (kptr64)(r + 2);
+    const int t0 = (int)r[0], t1 = (int)r[1];
+    int m[2][2] = {{0, 0}, {0, 0}}, z[2][2] = {{0, 0}, {0, 0}};
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+        for (int k = 0; k < CW; k++) {
+          kptr64 wk = rw + ((ky * 3 + kx) * CW + k) * WPL;
+#pragma unroll
+          for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+            for (int dx = 0; dx < 2; dx++)
+              mac<ARITH>(m[dy][dx], z[dy][dx], ws[dy + ky][dx + kx][k], wz[dy + ky][dx + kx][PL == 2 ? k : 0], wk);
+        }
+    int v[2][2];
+#pragma unroll
+    for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+      for (int dx = 0; dx < 2; dx++) v[dy][dx] = finish<ARITH>(m[dy][dx], z[dy][dx], nzt[dy][dx]);
+    if constexpr (POOL) {
+      const int p = pool2<ARITH>(pool2<ARITH>(v[0][0], v[0][1]), pool2<ARITH>(v[1][0], v[1][1]));
+      push_bits<OUT2>(b0[0], b1[0], fires<ARITH>(p, t0), fires<ARITH>(p, t1), 1u << c);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        push_bits<OUT2>(b0[i], b1[i], fires<ARITH>(v[i >> 1][i & 1], t0), fires<ARITH>(v[i >> 1][i & 1], t1), 1u << c);
+    }
+  }
+  const int groups = gridDim.y;
+  if constexpr (POOL) {
+    store_bits<OUT2>(out, (size_t)item, groups, blockIdx.y, b0[0], b1[0]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const size_t pix = (size_t)img * OD * OD + (size_t)(2 * qy + (i >> 1)) * OD + 2 * qx + (i & 1);
+      store_bits<OUT2>(out, pix, groups, blockIdx.y, b0[i], b1[i]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Generic "KW words in, thresholded bits out": one lane = one vector.
+//   * FC layers (StreamingFCLayer_Batch, top.cpp:228-231, lfc top.cpp:156-163):
+//     vector = image, KW = MW/64.
+//   * CNV layer 5 (3x3x256 -> 1x1x256): the window IS the whole map, already in
+//     (ky,kx,c) order in memory -> KW = 36.
+//   * CNV layer 4 (5x5x128 -> 3x3x256, SINGLE=true): vector = output pixel, its
+//     3x3 window gathered from the map (ID = 5, CW = 2 -> KW = 18).
+// ---------------------------------------------------------------------------
+template <int ARITH, int KW, bool OUT2, bool SINGLE, int CW, int ID>
+__global__ __launch_bounds__(kBlock) void k_vec(const uint64_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                 const uint32_t *__restrict__ rows, int n_items) {
+  constexpr int PL = planes_in<ARITH>(), WPL = wplanes<ARITH>();
+  constexpr int ROW_DW = 2 + 2 * KW * WPL;
+  const int item = blockIdx.x * kBlock + threadIdx.x;
+  if (item >= n_items) return;
+  uint64_t as[KW], az[PL == 2 ? KW : 1];
+  if constexpr (SINGLE) {
+    constexpr int OD = ID - 2;
+    static_assert(KW == 9 * CW, "window size");
+    const int img = item / (OD * OD), p = item - img * (OD * OD);
+    const int oy = p / OD, ox = p - oy * OD;
+    const uint64_t *__restrict__ base = in + ((size_t)img * ID * ID + (size_t)oy * ID + ox) * CW * PL;
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+        for (int k = 0; k < CW; k++) {
+          as[(ky * 3 + kx) * CW + k] = base[((ky * ID + kx) * CW + k) * PL];
+          if constexpr (PL == 2) az[(ky * 3 + kx) * CW + k] = base[((ky * ID + kx) * CW + k) * PL + 1];
+        }
+  } else {
+    const uint64_t *__restrict__ base = in + (size_t)item * KW * PL;
+#pragma unroll
+    for (int k = 0; k < KW; k++) {
+      as[k] = base[k * PL];
+      if constexpr (PL == 2) az[k] = base[k * PL + 1];
+    }
+  }
+  int nzt = 0;
+  if constexpr (ARITH == AR_TB) {
+#pragma unroll
+    for (int k = 0; k < KW; k++) nzt += pc64(az[k]);
+  }
+  kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)blockIdx.y * 32 * ROW_DW);
+  uint32_t b0 = 0, b1 = 0;
+  for (int c = 0; c < 32; c++) {
+    kptr32 r = w + c * ROW_DW;
+    kptr64 rw = (kptr64)(r + 2);
+    int m = 0, z = 0;
+#pragma unroll
+    for (int k = 0; k < KW; k++) mac<ARITH>(m, z, as[k], az[PL == 2 ? k : 0], rw + k * WPL);
+    const int v = finish<ARITH>(m, z, nzt);
+    push_bits<OUT2>(b0, b1, fires<ARITH>(v, (int)r[0]), fires<ARITH>(v, (int)r[1]), 1u << c);
+  }
+  store_bits<OUT2>(out, (size_t)item, gridDim.y, blockIdx.y, b0, b1);
+}
+
+// ---------------------------------------------------------------------------
+// CNV layer 8: 512 -> 64 raw accumulators (PassThroughActivation<ap_uint<16>>,
+// top.cpp:232-235) + the batched class decode of
+// testPrebuiltCIFAR10_multiple_images (foldedmv-offload.h:396-408): first
+// strict maximum over the first number_class scores, floored at 0.
+// AR_XNOR score = popcount of matches = MW - m; ternary nets: the signed sum.
+// ---------------------------------------------------------------------------
+template <int ARITH, int KW>
+__global__ __launch_bounds__(kBlock) void k_fclast(const uint64_t *__restrict__ in, int16_t *__restrict__ scores,
+                                                    int32_t *__restrict__ classes, const uint32_t *__restrict__ rows,
+                                                    int n_items, int number_class) {
+  constexpr int PL = planes_in<ARITH>(), WPL = wplanes<ARITH>();
+  constexpr int ROW_DW = 2 + 2 * KW * WPL;
+  const int item = blockIdx.x * kBlock + threadIdx.x;
+  if (item >= n_items) return;
+  uint64_t as[KW], az[PL == 2 ? KW : 1];
+  const uint64_t *__restrict__ base = in + (size_t)item * KW * PL;
+#pragma unroll
+  for (int k = 0; k < KW; k++) {
+    as[k] = base[k * PL];
+    if constexpr (PL == 2) az[k] = base[k * PL + 1];
+  }
+  int nzt = 0;
+  if constexpr (ARITH == AR_TB) {
+#pragma unroll
+    for (int k = 0; k < KW; k++) nzt += pc64(az[k]);
+  }
+  kptr32 w = (kptr32)(uintptr_t)rows;
+  uint32_t *__restrict__ s32 = reinterpret_cast<uint32_t *>(scores) + (size_t)item * 32;
+  int best = 0, bestv = 0;
+  uint32_t lo = 0;
+  for (int n = 0; n < 64; n++) {
+    kptr64 rw = (kptr64)(w + n * ROW_DW + 2);
+    int m = 0, z = 0;
+#pragma unroll
+    for (int k = 0; k < KW; k++) mac<ARITH>(m, z, as[k], az[PL == 2 ? k : 0], rw + k * WPL);
+    int s = (ARITH == AR_XNOR) ? (KW * 64 - m) : finish<ARITH>(m, z, nzt);
+    s = (int)(int16_t)s;  // 16-bit output word read back as ap_int<16>
+    if (n < number_class && s > bestv) { bestv = s; best = n; }
+    if (scores) {
+      if (n & 1) s32[n >> 1] = lo | ((uint32_t)(uint16_t)s << 16);
+      else lo = (uint32_t)(uint16_t)s;
+    }
+  }
+  if (classes) classes[item] = best;
+}
+
+// ---------------------------------------------------------------------------
+// LFC input: binarizeAndPack (foldedmv-offload.cpp:82-98) on the GPU.
+// 784 uint8 -> 13 words, bit i = (p >= 128), bits 784..831 zero.  One lane per
+// output word: 4 x 16-byte loads, coalesced across the wave.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t msb4(uint32_t d) { return (((d >> 7) & 0x01010101u) * 0x01020408u) >> 24; }
+
+__global__ __launch_bounds__(kBlock) void k_lfc_binarize(const uint8_t *__restrict__ imgs, uint64_t *__restrict__ out,
+                                                          int n_words) {
+  const int t = blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n_words) return;
+  const int img = t / 13, k = t - img * 13;
+  const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(imgs + (size_t)img * 784 + k * 64);
+  const int nq = (k == 12) ? 1 : 4;  // word 12 holds pixels 768..783 only
+  uint64_t word = 0;
+  for (int q = 0; q < nq; q++) {
+    const uint4 v = src[q];
+    const uint32_t bits = msb4(v.x) | (msb4(v.y) << 4) | (msb4(v.z) << 8) | (msb4(v.w) << 12);
+    word |= (uint64_t)bits << (16 * q);
+  }
+  out[t] = word;
+}
+
+// LFC output decode, batched form (testPrebinarized_nolabel_multiple_images,
+// foldedmv-offload.cpp:202-220): mask to number_class bits, class = index of
+// the highest set bit, 0 when none.  (unsigned)log2((double)w) equals that
+// index exactly while w < 2^47; the host decodes larger label sets itself.
+__global__ __launch_bounds__(kBlock) void k_lfc_decode(const uint64_t *__restrict__ words, int32_t *__restrict__ classes,
+                                                        int n, int number_class) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t mask = ~0ull >> (64 - number_class);
+  const uint64_t w = words[i] & mask;
+  classes[i] = w ? 63 - __builtin_clzll(w) : 0;
+}
+
+inline dim3 grid_for(long long items, int groups) { return dim3((unsigned)((items + kBlock - 1) / kBlock), (unsigned)groups); }
+
+#define BNN_LAUNCH(kern, grid, stream, ...)                                   \
+  do {                                                                        \
+    if ((grid).x > 0) hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, stream, __VA_ARGS__); \
+  } while (0)
+// stage boundary: with profiling on, an event separates consecutive stages
+#define BNN_MARK(ev, i, stream)                          \
+  do {                                                   \
+    if (ev) (void)hipEventRecord((ev)[i], stream);       \
+  } while (0)
+
+template <int ARITH, bool OUT2>
+void run_cnv_t(const CnvLaunch &a) {
+  const long long n = a.n;
+  uint32_t *A = reinterpret_cast<uint32_t *>(a.buf0), *B = reinterpret_cast<uint32_t *>(a.buf1);
+  const uint64_t *A64 = reinterpret_cast<const uint64_t *>(a.buf0), *B64 = reinterpret_cast<const uint64_t *>(a.buf1);
+  hipStream_t s = a.stream;
+  BNN_MARK(a.events, 0, s);
+  BNN_LAUNCH((k_conv0<OUT2>), grid_for(n * 900, 2), s, a.images, A, a.rows[0], (int)(n * 900));
+  BNN_MARK(a.events, 1, s);
+  BNN_LAUNCH((k_quad<ARITH, 1, 30, true, OUT2>), grid_for(n * 196, 2), s, A64, B, a.rows[1], (int)(n * 196));
+  BNN_MARK(a.events, 2, s);
+  BNN_LAUNCH((k_quad<ARITH, 1, 14, false, OUT2>), grid_for(n * 36, 4), s, B64, A, a.rows[2], (int)(n * 36));
+  BNN_MARK(a.events, 3, s);
+  BNN_LAUNCH((k_quad<ARITH, 2, 12, true, OUT2>), grid_for(n * 25, 4), s, A64, B, a.rows[3], (int)(n * 25));
+  BNN_MARK(a.events, 4, s);
+  BNN_LAUNCH((k_vec<ARITH, 18, OUT2, true, 2, 5>), grid_for(n * 9, 8), s, B64, A, a.rows[4], (int)(n * 9));
+  BNN_MARK(a.events, 5, s);
+  BNN_LAUNCH((k_vec<ARITH, 36, OUT2, false, 1, 1>), grid_for(n, 8), s, A64, B, a.rows[5], (int)n);
+  BNN_MARK(a.events, 6, s);
+  BNN_LAUNCH((k_vec<ARITH, 4, OUT2, false, 1, 1>), grid_for(n, 16), s, B64, A, a.rows[6], (int)n);
+  BNN_MARK(a.events, 7, s);
+  BNN_LAUNCH((k_vec<ARITH, 8, OUT2, false, 1, 1>), grid_for(n, 16), s, A64, B, a.rows[7], (int)n);
+  BNN_MARK(a.events, 8, s);
+  BNN_LAUNCH((k_fclast<ARITH, 8>), grid_for(n, 1), s, B64, a.scores, a.classes, a.rows[8], (int)n, a.number_class);
+  BNN_MARK(a.events, 9, s);
+}
+
+}  // namespace
+
+const char *stage_name(bool is_cnv, int stage) {
+  static const char *cnv[kCnvStages] = {"k_conv0 (L0)", "k_quad L1+pool", "k_quad L2", "k_quad L3+pool", "k_vec L4",
+                                        "k_vec L5", "k_vec L6", "k_vec L7", "k_fclast L8+decode"};
+  static const char *lfc[kLfcStages] = {"k_lfc_binarize", "k_vec L0", "k_vec L1", "k_vec L2", "k_vec L3", "k_lfc_decode"};
+  if (stage < 0 || stage >= (is_cnv ? kCnvStages : kLfcStages)) return "";
+  return is_cnv ? cnv[stage] : lfc[stage];
+}
+
+// per-image bytes of the two ping-pong activation buffers
+void cnv_workspace_bytes(int abits, size_t *buf0, size_t *buf1) {
+  *buf0 = 900 * 8 * (size_t)abits;  // L0 out 30x30x64 (largest of the even stages)
+  *buf1 = 196 * 8 * (size_t)abits;  // L1 out 14x14x64 (largest of the odd stages)
+}
+void lfc_workspace_bytes(int abits, size_t *buf0, size_t *buf1) {
+  *buf0 = 128 * (size_t)abits;  // 1024 activations
+  *buf1 = 128 * (size_t)abits;
+}
+
+hipError_t run_cnv(NetId net, const CnvLaunch &a) {
+  if (a.n <= 0) return hipSuccess;
+  switch (net) {
+    case NET_CNVW1A1: run_cnv_t<AR_XNOR, false>(a); break;
+    case NET_CNVW1A2: run_cnv_t<AR_TB, true>(a); break;
+    case NET_CNVW2A2: run_cnv_t<AR_TT, true>(a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t run_lfc(NetId net, const LfcLaunch &a) {
+  if (a.n <= 0) return hipSuccess;
+  const long long n = a.n;
+  uint32_t *A = reinterpret_cast<uint32_t *>(a.buf0), *B = reinterpret_cast<uint32_t *>(a.buf1);
+  uint64_t *A64 = reinterpret_cast<uint64_t *>(a.buf0), *B64 = reinterpret_cast<uint64_t *>(a.buf1);
+  hipStream_t s = a.stream;
+  BNN_MARK(a.events, 0, s);
+  BNN_LAUNCH(k_lfc_binarize, grid_for(n * 13, 1), s, a.images, A64, (int)(n * 13));
+  BNN_MARK(a.events, 1, s);
+  if (net == NET_LFCW1A1) {
+    BNN_LAUNCH((k_vec<AR_XNOR, 13, false, false, 1, 1>), grid_for(n, 32), s, A64, B, a.rows[0], (int)n);
+    BNN_MARK(a.events, 2, s);
+    BNN_LAUNCH((k_vec<AR_XNOR, 16, false, false, 1, 1>), grid_for(n, 32), s, B64, A, a.rows[1], (int)n);
+    BNN_MARK(a.events, 3, s);
+    BNN_LAUNCH((k_vec<AR_XNOR, 16, false, false, 1, 1>), grid_for(n, 32), s, A64, B, a.rows[2], (int)n);
+    BNN_MARK(a.events, 4, s);
+    BNN_LAUNCH((k_vec<AR_XNOR, 16, false, false, 1, 1>), grid_for(n, 2), s, B64, reinterpret_cast<uint32_t *>(a.words), a.rows[3], (int)n);
+    BNN_MARK(a.events, 5, s);
+  } else if (net == NET_LFCW1A2) {
+    BNN_LAUNCH((k_vec<AR_XNOR, 13, true, false, 1, 1>), grid_for(n, 32), s, A64, B, a.rows[0], (int)n);
+    BNN_MARK(a.events, 2, s);
+    BNN_LAUNCH((k_vec<AR_TB, 16, true, false, 1, 1>), grid_for(n, 32), s, B64, A, a.rows[1], (int)n);
+    BNN_MARK(a.events, 3, s);
+    BNN_LAUNCH((k_vec<AR_TB, 16, true, false, 1, 1>), grid_for(n, 32), s, A64, B, a.rows[2], (int)n);
+    BNN_MARK(a.events, 4, s);
+    BNN_LAUNCH((k_vec<AR_TB, 16, false, false, 1, 1>), grid_for(n, 2), s, B64, reinterpret_cast<uint32_t *>(a.words), a.rows[3], (int)n);
+    BNN_MARK(a.events, 5, s);
+  } else {
+    return hipErrorInvalidValue;
+  }
+  if (a.classes) BNN_LAUNCH(k_lfc_decode, grid_for(n, 1), s, a.words, a.classes, (int)n, a.number_class);
+  BNN_MARK(a.events, 6, s);
+  return hipGetLastError();
+}
+
+}  // namespace bnn

@@ -1,0 +1,164 @@
+// packed_params.cpp -- bnn/params files -> device blob (host only, no HIP).
+#include "packed_params.h"
+
+#include <cstdio>
+#include <cstring>
+
+namespace bnn {
+namespace {
+
+// One PE memory file: `n` little-endian 64-bit words, zero-filled when short.
+bool read_pe_file(const std::string &path, std::vector<uint64_t> &dst, size_t n) {
+  dst.assign(n, 0);
+  FILE *f = std::fopen(path.c_str(), "rb");
+  if (!f) return false;
+  std::vector<unsigned char> raw(n * 8, 0);
+  const size_t got = std::fread(raw.data(), 1, raw.size(), f);
+  std::fclose(f);
+  // istream::read on a short file stores the bytes it got (rest of `e` stays 0) and
+  // fails every later read: identical to decoding the zero-padded buffer.
+  const size_t full = (got + 7) / 8;
+  for (size_t i = 0; i < full; i++) {
+    uint64_t e = 0;
+    for (int k = 7; k >= 0; k--) e = (e << 8) | raw[i * 8 + k];
+    dst[i] = e;
+  }
+  return true;
+}
+
+inline int32_t floor_div2(int32_t v) { return v >> 1; }  // arithmetic shift == floor for negatives
+
+// logical weight (value domain) of neuron n, column j, from the PE memories
+struct LayerFiles {
+  const LayerSpec *L;
+  std::vector<std::vector<uint64_t>> w, t;  // per PE
+  int weight(int n, int j) const {
+    const int pe = n % L->fold.pe, nf = n / L->fold.pe;
+    const int sf_count = L->fold.wmem / L->fold.tmem;
+    const int sf = j / L->fold.simd, s = j % L->fold.simd;
+    const uint64_t word = w[pe][(size_t)nf * sf_count + sf];
+    if (L->wbits == 1) return ((word >> s) & 1) ? 1 : -1;
+    const int f = (int)((word >> (2 * s)) & 3);  // ap_int<2>
+    return f >= 2 ? f - 4 : f;
+  }
+  int32_t threshold(int n, int i) const {
+    const int pe = n % L->fold.pe, nf = n / L->fold.pe;
+    const uint64_t e = t[pe][(size_t)nf * L->nthr + i];
+    if (L->thr24) {  // ap_fixed<64,56> bits assigned to ap_fixed<24,16>: low 24 bits, sign-extended
+      int32_t v = (int32_t)(e & 0xFFFFFF);
+      return (v & 0x800000) ? v - 0x1000000 : v;
+    }
+    return (int16_t)(e & 0xFFFF);  // ap_uint<64> assigned to ap_int<16>
+  }
+};
+
+}  // namespace
+
+uint32_t row_dwords_for(const LayerSpec &L) {
+  const uint32_t kw = (uint32_t)L.mw() / 64;
+  switch (L.arith) {
+    case AR_INT8: return 12;
+    case AR_XNOR: return 2 + 2 * kw;
+    case AR_TB: return 2 + 2 * kw;
+    case AR_TT: return 2 + 4 * kw;
+  }
+  return 0;
+}
+
+std::string pack_params_from_dir(const NetSpec &net, const std::string &dir, std::vector<uint8_t> &blob) {
+  PackedHeader h{};
+  h.magic0 = kBlobMagic0; h.magic1 = kBlobMagic1; h.version = kBlobVersion;
+  h.net_id = (uint32_t)net.id; h.nlayers = (uint32_t)net.nlayers;
+  uint32_t off = (sizeof(PackedHeader) + 255u) & ~255u;
+  for (int l = 0; l < net.nlayers; l++) {
+    const LayerSpec &L = net.L[l];
+    h.layer[l].offset = off;
+    h.layer[l].row_dwords = row_dwords_for(L);
+    h.layer[l].rows = (uint32_t)L.mh();
+    h.layer[l].kw = (L.arith == AR_INT8) ? 0 : (uint32_t)L.mw() / 64;
+    off += h.layer[l].row_dwords * 4 * h.layer[l].rows;
+    off = (off + 255u) & ~255u;
+  }
+  h.total_bytes = off + 256;  // tail slack: wide scalar loads may run past the last row
+  blob.assign(h.total_bytes, 0);
+  std::memcpy(blob.data(), &h, sizeof(h));
+
+  for (int l = 0; l < net.nlayers; l++) {
+    const LayerSpec &L = net.L[l];
+    LayerFiles F;
+    F.L = &L;
+    F.w.resize(L.fold.pe);
+    F.t.resize(L.fold.pe);
+    for (int pe = 0; pe < L.fold.pe; pe++) {
+      const std::string stem = dir + "/" + std::to_string(l) + "-" + std::to_string(pe);
+      if (!read_pe_file(stem + "-weights.bin", F.w[pe], (size_t)L.fold.wmem))
+        return "Could not open file " + stem + "-weights.bin";
+      if (L.nthr > 0 && !read_pe_file(stem + "-thres.bin", F.t[pe], (size_t)L.fold.tmem * L.nthr))
+        return "Could not open file " + stem + "-thres.bin";
+    }
+    const int MW = L.mw(), MH = L.mh();
+    const uint32_t rd = h.layer[l].row_dwords;
+    uint32_t *rows = reinterpret_cast<uint32_t *>(blob.data() + h.layer[l].offset);
+    for (int n = 0; n < MH; n++) {
+      uint32_t *row = rows + (size_t)n * rd;
+      // thresholds
+      int32_t T[2] = {0, 0};
+      for (int i = 0; i < L.nthr && i < 2; i++) T[i] = F.threshold(n, i);
+      if (L.nthr == 1) T[1] = T[0];
+      int32_t t[2];
+      for (int i = 0; i < 2; i++) {
+        if (L.arith == AR_INT8) t[i] = floor_div2(T[i]);
+        else if (L.arith == AR_XNOR) t[i] = L.signed_bb ? floor_div2(MW - T[i] + 1) : (MW - T[i]);
+        else t[i] = T[i];
+      }
+      row[0] = (uint32_t)t[0];
+      row[1] = (uint32_t)t[1];
+      // weights
+      if (L.arith == AR_INT8) {
+        for (int c = 0; c < 3; c++)
+          for (int ky = 0; ky < 3; ky++) {
+            uint32_t d = 0;
+            for (int kx = 0; kx < 3; kx++) {
+              const int wv = F.weight(n, (ky * 3 + kx) * 3 + c);
+              d |= (uint32_t)(uint8_t)(int8_t)wv << (8 * kx);
+            }
+            row[2 + c * 3 + ky] = d;
+          }
+      } else {
+        uint64_t *wq = reinterpret_cast<uint64_t *>(row + 2);
+        const int kw = MW / 64;
+        for (int k = 0; k < kw; k++) {
+          uint64_t pos = 0, neg = 0, nz = 0;
+          for (int b = 0; b < 64; b++) {
+            const int wv = F.weight(n, k * 64 + b);
+            if (wv > 0) pos |= 1ull << b;
+            if (wv < 0) neg |= 1ull << b;
+            if (wv != 0) nz |= 1ull << b;
+          }
+          if (L.arith == AR_XNOR) wq[k] = pos;
+          else if (L.arith == AR_TB) wq[k] = neg;
+          else { wq[2 * k] = neg; wq[2 * k + 1] = nz; }
+        }
+      }
+    }
+  }
+  return "";
+}
+
+std::string validate_blob(const NetSpec &net, const void *blob, size_t bytes) {
+  if (bytes < sizeof(PackedHeader)) return "packed params: blob shorter than its header";
+  PackedHeader h;
+  std::memcpy(&h, blob, sizeof(h));
+  if (h.magic0 != kBlobMagic0 || h.magic1 != kBlobMagic1) return "packed params: bad magic";
+  if (h.version != kBlobVersion) return "packed params: version mismatch";
+  if (h.net_id != (uint32_t)net.id) return std::string("packed params: blob is not for network ") + net.name;
+  if (h.nlayers != (uint32_t)net.nlayers || h.total_bytes != bytes) return "packed params: size mismatch";
+  for (int l = 0; l < net.nlayers; l++) {
+    const PackedLayer &p = h.layer[l];
+    if (p.row_dwords != row_dwords_for(net.L[l]) || p.rows != (uint32_t)net.L[l].mh()) return "packed params: layer shape mismatch";
+    if ((size_t)p.offset + (size_t)p.row_dwords * 4 * p.rows > bytes) return "packed params: layer out of bounds";
+  }
+  return "";
+}
+
+}  // namespace bnn

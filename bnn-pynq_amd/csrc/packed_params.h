@@ -1,0 +1,73 @@
+// packed_params.h -- the device-resident parameter blob.
+//
+// load_parameters() reads the reference's bnn/params/<dataset>/<net>/
+// L-P-weights.bin / L-P-thres.bin files unchanged (format: SURVEY.md A1;
+// reader being replaced: FoldedMVLoadLayerMem, bnn/src/library/host/
+// foldedmv-offload.cpp:281-336) and repacks them ONCE into this blob: one
+// contiguous, position-independent byte string (offsets, no pointers) that is
+// uploaded to HBM, and that rank 0 can broadcast to the other GPUs over RCCL
+// as plain bytes.
+//
+// Layout of a layer = `rows` neuron rows of `row_dwords` 32-bit words, neuron
+// n at row n (the PE interleave of the files is undone).  A row is what ONE
+// wave needs to evaluate one neuron for 64 work items, laid out so that it is
+// fetched with a couple of wide scalar loads (s_load_dwordx8/x16) and then
+// used straight from SGPRs as the scalar operand of v_xor / v_and / v_dot4:
+//
+//   dword 0,1      t0, t1   pre-transformed thresholds (see below)
+//   dword 2..      the weight words of the row
+//
+//   AR_INT8   9 dwords, dword (c*3+ky) = bytes {w[ky][0][c], w[ky][1][c], w[ky][2][c], 0}
+//             as int8 in {-1,0,+1}; 1 pad dword.         fire_i = t_i < dot
+//             t_i = floor(T_i / 2)   (T in 2^-8 units, accumulator = 2*dot)
+//   AR_XNOR   KW x u64, bit j = 1 <=> weight +1.  m = popcount(w ^ a) = # mismatches
+//             fire_i = m < t_i,  t_i = MW - T_i           (T_i < MW - m)
+//             signed form (lfcW1A2 L0): t_i = floor((MW - T_i + 1) / 2)   (T_i < MW - 2m)
+//   AR_TB     KW x u64, bit j = 1 <=> weight -1.  acc = nz(a) - 2*popcount(za & (sa ^ w))
+//             fire_i = T_i < acc
+//   AR_TT     KW x {u64 sign (1 <=> -1), u64 non-zero}.
+//             acc = popcount(z) - 2*popcount(z & (sa ^ sw)),  z = za & zw;  fire_i = T_i < acc
+//
+// Column order j inside a row is the reference's: conv (ky*3+kx)*Cin + c, i.e.
+// window pixel-major, channel-minor -- exactly the order in which the
+// bit-packed HWC activation words of a 3x3 window are laid out.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "topology.h"
+
+namespace bnn {
+
+constexpr uint32_t kBlobMagic0 = 0x4D4E4E42u;  // "BNNM"
+constexpr uint32_t kBlobMagic1 = 0x35353349u;  // "I355"
+constexpr uint32_t kBlobVersion = 1;
+
+struct PackedLayer {
+  uint32_t offset;      // bytes from blob start, 256-byte aligned
+  uint32_t row_dwords;
+  uint32_t rows;        // MH
+  uint32_t kw;          // 64-bit words per activation plane (AR_INT8: 0)
+};
+
+struct PackedHeader {
+  uint32_t magic0, magic1, version, net_id;
+  uint32_t nlayers, total_bytes, reserved0, reserved1;
+  PackedLayer layer[9];
+};
+static_assert(sizeof(PackedHeader) == 32 + 9 * 16, "blob header layout");
+
+uint32_t row_dwords_for(const LayerSpec &L);
+
+// Reads the param directory and fills `blob`.  Returns "" on success, else the
+// error text (missing file: the reference throws "Could not open file",
+// foldedmv-offload.cpp:321-323).  Short files are zero-filled like the
+// reference's reader (foldedmv-offload.cpp:283-284).
+std::string pack_params_from_dir(const NetSpec &net, const std::string &dir, std::vector<uint8_t> &blob);
+
+// Sanity-check a blob received from elsewhere (e.g. an RCCL broadcast).
+std::string validate_blob(const NetSpec &net, const void *blob, size_t bytes);
+
+}  // namespace bnn

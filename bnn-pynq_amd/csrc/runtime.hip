@@ -1,0 +1,472 @@
+// runtime.hip -- host side of the MI355X runtime: device state, workspace,
+// batch chunking, timing, output decode, and the C ABI of include/bnn_mi355x.h.
+//
+// Host-side reference code this replaces (the RAWHLS half of
+// bnn/src/library/host/foldedmv-offload.{h,cpp} and rawhls-offload.cpp, plus
+// the per-network bnn/src/network/<net>/sw/main_python.cpp):
+//   FoldedMVInit / FoldedMVDeinit            -> Workspace (HBM buffers, lazily sized)
+//   FoldedMVLoadLayerMem / DoMemInit         -> packed_params.cpp + one hipMemcpy
+//   parse_cifar10 / parse_mnist_images       -> read_cifar_file / read_mnist_file
+//   quantiseAndPack / binarizeAndPack        -> done on the GPU (k_conv0 / k_lfc_binarize)
+//   BlackBoxJam(.., numReps)                 -> run_cnv / run_lfc (kernels.hip)
+//   copyFromLowPrecBuffer + argmax / log2    -> k_fclast / host decode below
+//
+// There is no CPU compute path in this library: without a usable HIP device
+// every inference entry point fails loudly (message on stderr, NULL / -1).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/bnn_mi355x.h"
+#include "kernels.h"
+#include "packed_params.h"
+#include "topology.h"
+
+#ifndef BNN_NETWORK
+#error "compile with -DBNN_NETWORK=NET_CNVW1A1 (or another bnn::NetId)"
+#endif
+
+namespace bnn {
+namespace {
+
+constexpr int kMaxChunk = 131072;  // images per pass through the stages
+
+struct Runtime {
+  const NetSpec &spec = net_spec(BNN_NETWORK);
+  int device = -1;  // -1: whatever HIP's current device is
+  std::string err;
+  // parameters
+  std::vector<uint8_t> blob;
+  void *d_blob = nullptr;
+  const uint32_t *rows[9] = {};
+  // workspace
+  int cap = 0;
+  void *buf0 = nullptr, *buf1 = nullptr;
+  uint8_t *d_images = nullptr;
+  int16_t *d_scores = nullptr;
+  int32_t *d_classes = nullptr;
+  uint64_t *d_words = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // optional per-stage profiling (bnn_mi355x_profile): one event set per enqueued chunk
+  bool profiling = false;
+  std::vector<std::vector<hipEvent_t>> prof_sets;
+  size_t prof_used = 0;
+};
+
+Runtime &rt() {
+  static Runtime r;
+  return r;
+}
+
+int fail(const std::string &msg) {
+  rt().err = msg;
+  std::fprintf(stderr, "bnn-mi355x[%s]: %s\n", rt().spec.name, msg.c_str());
+  return -1;
+}
+
+#define HIP_OK(expr)                                                                     \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) return fail(std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+int bind_device() {
+  Runtime &r = rt();
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return fail("no HIP device available: this runtime has no CPU fallback");
+  if (r.device >= 0) HIP_OK(hipSetDevice(r.device));
+  if (!r.stream) {
+    HIP_OK(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+    HIP_OK(hipEventCreate(&r.ev0));
+    HIP_OK(hipEventCreate(&r.ev1));
+  }
+  return 0;
+}
+
+int upload_blob() {
+  Runtime &r = rt();
+  if (bind_device()) return -1;
+  if (r.d_blob) { HIP_OK(hipFree(r.d_blob)); r.d_blob = nullptr; }
+  HIP_OK(hipMalloc(&r.d_blob, r.blob.size()));
+  HIP_OK(hipMemcpy(r.d_blob, r.blob.data(), r.blob.size(), hipMemcpyHostToDevice));
+  const PackedHeader *h = reinterpret_cast<const PackedHeader *>(r.blob.data());
+  for (int l = 0; l < r.spec.nlayers; l++)
+    r.rows[l] = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(r.d_blob) + h->layer[l].offset);
+  return 0;
+}
+
+void free_workspace() {
+  Runtime &r = rt();
+  if (r.cap == 0) return;
+  if (r.device >= 0) (void)hipSetDevice(r.device);
+  (void)hipFree(r.buf0); (void)hipFree(r.buf1); (void)hipFree(r.d_images);
+  (void)hipFree(r.d_scores); (void)hipFree(r.d_classes); (void)hipFree(r.d_words);
+  r.buf0 = r.buf1 = nullptr; r.d_images = nullptr; r.d_scores = nullptr; r.d_classes = nullptr; r.d_words = nullptr;
+  r.cap = 0;
+}
+
+// workspace for `n` images per pass (at most kMaxChunk)
+int reserve(int n) {
+  Runtime &r = rt();
+  if (n > kMaxChunk) n = kMaxChunk;
+  if (n <= r.cap) return 0;
+  if (bind_device()) return -1;
+  free_workspace();
+  size_t b0, b1;
+  if (r.spec.is_cnv) cnv_workspace_bytes(r.spec.abits, &b0, &b1);
+  else lfc_workspace_bytes(r.spec.abits, &b0, &b1);
+  const size_t N = (size_t)n;
+  HIP_OK(hipMalloc(&r.buf0, N * b0 + 256));
+  HIP_OK(hipMalloc(&r.buf1, N * b1 + 256));
+  HIP_OK(hipMalloc(reinterpret_cast<void **>(&r.d_images), N * r.spec.image_bytes() + 256));
+  HIP_OK(hipMalloc(reinterpret_cast<void **>(&r.d_scores), N * 64 * sizeof(int16_t)));
+  HIP_OK(hipMalloc(reinterpret_cast<void **>(&r.d_classes), N * sizeof(int32_t)));
+  HIP_OK(hipMalloc(reinterpret_cast<void **>(&r.d_words), N * sizeof(uint64_t)));
+  r.cap = n;
+  return 0;
+}
+
+// enqueue one chunk (n <= cap) whose images are already in HBM
+int enqueue(const uint8_t *d_imgs, int n, int ncls, int32_t *d_classes, int16_t *d_scores, uint64_t *d_words,
+            hipStream_t s) {
+  Runtime &r = rt();
+  hipError_t e;
+  hipEvent_t *evs = nullptr;
+  if (r.profiling) {
+    const int need = (r.spec.is_cnv ? kCnvStages : kLfcStages) + 1;
+    if (r.prof_used == r.prof_sets.size()) {
+      std::vector<hipEvent_t> set(need);
+      for (auto &ev : set) HIP_OK(hipEventCreate(&ev));
+      r.prof_sets.push_back(set);
+    }
+    evs = r.prof_sets[r.prof_used++].data();
+  }
+  if (r.spec.is_cnv) {
+    CnvLaunch a{};
+    a.images = d_imgs; a.n = n; a.buf0 = r.buf0; a.buf1 = r.buf1;
+    for (int l = 0; l < 9; l++) a.rows[l] = r.rows[l];
+    a.scores = d_scores; a.classes = d_classes; a.number_class = ncls; a.stream = s; a.events = evs;
+    e = run_cnv(r.spec.id, a);
+  } else {
+    LfcLaunch a{};
+    a.images = d_imgs; a.n = n; a.buf0 = r.buf0; a.buf1 = r.buf1;
+    for (int l = 0; l < 4; l++) a.rows[l] = r.rows[l];
+    a.words = d_words ? d_words : r.d_words;
+    a.classes = d_classes; a.number_class = ncls; a.stream = s; a.events = evs;
+    e = run_lfc(r.spec.id, a);
+  }
+  if (e != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(e));
+  return 0;
+}
+
+bool ready() {
+  if (!rt().d_blob) { fail("load_parameters has not been called (or failed)"); return false; }
+  return true;
+}
+
+// n host images -> any of classes / scores / words (host arrays), chunked.
+// usec: device time of the compute stages only, per image (the reference times
+// the accelerator call alone, foldedmv-offload.h:389-392).
+int infer_host(const uint8_t *imgs, int n, int ncls, int32_t *classes, int16_t *scores, uint64_t *words, float *usec) {
+  Runtime &r = rt();
+  if (!ready()) return -1;
+  if (ncls < 1 || ncls > 64) return fail("number_class must be in 1..64");
+  double total_ms = 0.0;
+  const size_t isz = (size_t)r.spec.image_bytes();
+  for (int base = 0; base < n; base += kMaxChunk) {
+    const int m = (n - base < kMaxChunk) ? n - base : kMaxChunk;
+    if (reserve(m)) return -1;
+    HIP_OK(hipMemcpyAsync(r.d_images, imgs + (size_t)base * isz, (size_t)m * isz, hipMemcpyHostToDevice, r.stream));
+    HIP_OK(hipEventRecord(r.ev0, r.stream));
+    if (enqueue(r.d_images, m, ncls, classes ? r.d_classes : nullptr, (scores && r.spec.is_cnv) ? r.d_scores : nullptr,
+                r.d_words, r.stream))
+      return -1;
+    HIP_OK(hipEventRecord(r.ev1, r.stream));
+    if (classes) HIP_OK(hipMemcpyAsync(classes + base, r.d_classes, (size_t)m * 4, hipMemcpyDeviceToHost, r.stream));
+    if (scores && r.spec.is_cnv)
+      HIP_OK(hipMemcpyAsync(scores + (size_t)base * 64, r.d_scores, (size_t)m * 128, hipMemcpyDeviceToHost, r.stream));
+    if (words && !r.spec.is_cnv)
+      HIP_OK(hipMemcpyAsync(words + base, r.d_words, (size_t)m * 8, hipMemcpyDeviceToHost, r.stream));
+    HIP_OK(hipStreamSynchronize(r.stream));
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, r.ev0, r.ev1));
+    total_ms += ms;
+  }
+  if (usec) *usec = n > 0 ? (float)(total_ms * 1000.0 / n) : 0.f;
+  return 0;
+}
+
+// ---- input files ------------------------------------------------------------
+// CIFAR-10 binary: records of [label u8][R 1024][G 1024][B 1024] (tiny-cnn
+// parse_cifar10, call site main_python.cpp:129,152).  Bodies are passed to the
+// GPU as they are: planar CHW uint8.
+int read_cifar_file(const char *path, std::vector<uint8_t> &imgs) {
+  FILE *f = std::fopen(path, "rb");
+  if (!f) return fail(std::string("Could not open file ") + path);
+  std::vector<uint8_t> rec(3073);
+  imgs.clear();
+  int n = 0;
+  while (std::fread(rec.data(), 1, 3073, f) == 3073) {
+    imgs.insert(imgs.end(), rec.begin() + 1, rec.end());
+    n++;
+  }
+  std::fclose(f);
+  return n;
+}
+
+// MNIST idx3: 16-byte big-endian header (magic 0x803, count, rows, cols), then
+// count x 784 uint8 (tiny-cnn parse_mnist_images, lfcW1A1/sw/main_python.cpp:122,144)
+int read_mnist_file(const char *path, std::vector<uint8_t> &imgs) {
+  FILE *f = std::fopen(path, "rb");
+  if (!f) return fail(std::string("Could not open file ") + path);
+  unsigned char h[16];
+  if (std::fread(h, 1, 16, f) != 16) { std::fclose(f); return fail("MNIST image file: short header"); }
+  auto be = [&](int o) { return ((uint32_t)h[o] << 24) | ((uint32_t)h[o + 1] << 16) | ((uint32_t)h[o + 2] << 8) | h[o + 3]; };
+  if (be(0) != 0x803u || be(8) != 28 || be(12) != 28) { std::fclose(f); return fail("MNIST image file: bad header"); }
+  const uint32_t n = be(4);
+  imgs.assign((size_t)n * 784, 0);
+  const size_t got = n ? std::fread(imgs.data(), 1, imgs.size(), f) : 0;
+  std::fclose(f);
+  if (got != imgs.size()) return fail("MNIST image file: truncated");
+  return (int)n;
+}
+
+int read_images(const char *path, std::vector<uint8_t> &imgs) {
+  return rt().spec.is_cnv ? read_cifar_file(path, imgs) : read_mnist_file(path, imgs);
+}
+
+// ---- LFC host decode (libm, like the reference) -------------------------------
+uint64_t label_mask(int ncls) { return 0xFFFFFFFFFFFFFFFFull >> (64 - ncls); }
+// batched: (unsigned) log2((double) word), 0 when no bit is set (foldedmv-offload.cpp:213-220)
+int lfc_class_batched(uint64_t w, int ncls) {
+  w &= label_mask(ncls);
+  return w ? (int)(unsigned int)std::log2((double)w) : 0;
+}
+// single: index of the one-hot entry = round(log2(word)) (foldedmv-offload.cpp:152-165)
+int lfc_hot_single(uint64_t w, int ncls) {
+  w &= label_mask(ncls);
+  return w ? (int)(unsigned int)std::round(std::log2((double)w)) : 0;
+}
+
+int *classify_host(const uint8_t *imgs, int n, int ncls, float *usec, int enable_detail) {
+  Runtime &r = rt();
+  int *result = nullptr;
+  if (r.spec.is_cnv && enable_detail) {
+    std::vector<int16_t> s((size_t)n * 64);
+    if (infer_host(imgs, n, ncls, nullptr, s.data(), nullptr, usec)) return nullptr;
+    result = new (std::nothrow) int[(size_t)(n > 0 ? n : 1) * ncls];
+    if (!result) { fail("out of memory"); return nullptr; }
+    for (int i = 0; i < n; i++)
+      for (int j = 0; j < ncls; j++) result[(size_t)i * ncls + j] = s[(size_t)i * 64 + j];
+  } else if (r.spec.is_cnv) {
+    result = new (std::nothrow) int[(size_t)(n > 0 ? n : 1)];
+    if (!result) { fail("out of memory"); return nullptr; }
+    if (infer_host(imgs, n, ncls, result, nullptr, nullptr, usec)) { delete[] result; return nullptr; }
+  } else {
+    // the LFC libraries ignore enable_detail (lfcW1A1/sw/main_python.cpp:135-156)
+    std::vector<uint64_t> w((size_t)(n > 0 ? n : 1));
+    if (infer_host(imgs, n, ncls, nullptr, nullptr, w.data(), usec)) return nullptr;
+    result = new (std::nothrow) int[(size_t)(n > 0 ? n : 1)];
+    if (!result) { fail("out of memory"); return nullptr; }
+    for (int i = 0; i < n; i++) result[i] = lfc_class_batched(w[i], ncls);
+  }
+  return result;
+}
+
+}  // namespace
+}  // namespace bnn
+
+using namespace bnn;
+
+// ============================================================================ C ABI
+extern "C" {
+
+void load_parameters(const char *path) {
+  Runtime &r = rt();
+  std::printf("Setting network weights and thresholds in accelerator...\n");
+  std::vector<uint8_t> blob;
+  const std::string e = pack_params_from_dir(r.spec, path ? path : "", blob);
+  if (!e.empty()) { fail(e); return; }
+  r.blob.swap(blob);
+  if (upload_blob()) { r.blob.clear(); return; }
+  r.err.clear();
+}
+
+int inference(const char *path, int results[64], int number_class, float *usecPerImage) {
+  Runtime &r = rt();
+  if (!ready()) return -1;
+  std::vector<uint8_t> imgs;
+  const int n = read_images(path, imgs);
+  if (n < 0) return -1;
+  if (n == 0) return fail("no image in input file");
+  float usec = 0.f;
+  int cls;
+  if (r.spec.is_cnv) {
+    // testPrebuiltCIFAR10_from_image: count = 1 (foldedmv-offload.h:318)
+    int16_t s[64];
+    if (infer_host(imgs.data(), 1, number_class, nullptr, s, nullptr, &usec)) return -1;
+    if (results)
+      for (int j = 0; j < number_class; j++) results[j] = s[j];
+    cls = 0;
+    for (int j = 1; j < number_class; j++)
+      if (s[j] > s[cls]) cls = j;  // std::max_element: first maximum
+  } else {
+    uint64_t w = 0;
+    if (infer_host(imgs.data(), 1, number_class, nullptr, nullptr, &w, &usec)) return -1;
+    const int hot = lfc_hot_single(w, number_class);
+    if (results)
+      for (int i = 0; i < 64; i++) results[i] = (i == hot) ? 1 : 0;
+    cls = hot < 64 ? hot : 0;
+  }
+  std::printf("Inference took %.0f microseconds, %g usec per image\n", usec, usec);
+  std::printf("Classification rate: %g images per second\n", 1000000.0 / usec);
+  if (usecPerImage) *usecPerImage = usec;
+  return cls;
+}
+
+int *inference_multiple(const char *path, int number_class, int *image_number, float *usecPerImage,
+                        int enable_detail) {
+  if (!ready()) return nullptr;
+  std::vector<uint8_t> imgs;
+  const int n = read_images(path, imgs);
+  if (n < 0) return nullptr;
+  float usec = 0.f;
+  int *res = classify_host(imgs.data(), n, number_class, &usec, enable_detail);
+  if (!res) return nullptr;
+  std::printf("Inference took %.0f microseconds, %g usec per image\n", usec * n, usec);
+  std::printf("Classification rate: %g images per second\n", 1000000.0 / usec);
+  if (image_number) *image_number = n;
+  if (usecPerImage) *usecPerImage = usec;
+  return res;
+}
+
+int *inference_multiple_with_faults(const char *path, int number_class, int *image_number,
+                                    float *usecPerImage, unsigned int flip_count, int word_size,
+                                    int target, int *target_layers, unsigned int num_targets) {
+  (void)word_size; (void)target; (void)target_layers; (void)num_targets;
+  if (flip_count != 0) {
+    fail("fault injection (flip_count > 0) is not available in the MI355X runtime");
+    if (image_number) *image_number = 0;
+    return nullptr;
+  }
+  return inference_multiple(path, number_class, image_number, usecPerImage, 0);
+}
+
+void free_results(int *result) { delete[] result; }
+
+void deinit(void) { free_workspace(); }
+
+const char *bnn_mi355x_network(void) { return rt().spec.name; }
+int bnn_mi355x_image_bytes(void) { return rt().spec.image_bytes(); }
+const char *bnn_mi355x_last_error(void) { return rt().err.c_str(); }
+
+int bnn_mi355x_set_device(int ordinal) {
+  Runtime &r = rt();
+  if (r.d_blob || r.cap) return fail("set_device must be called before load_parameters");
+  r.device = ordinal;
+  return 0;
+}
+
+size_t bnn_mi355x_pack_params(const char *path, void *dst, size_t cap) {
+  std::vector<uint8_t> blob;
+  const std::string e = pack_params_from_dir(rt().spec, path ? path : "", blob);
+  if (!e.empty()) { fail(e); return 0; }
+  if (dst) {
+    if (cap < blob.size()) { fail("pack_params: destination too small"); return 0; }
+    std::memcpy(dst, blob.data(), blob.size());
+  }
+  return blob.size();
+}
+
+size_t bnn_mi355x_export_params(void *dst, size_t cap) {
+  Runtime &r = rt();
+  if (r.blob.empty()) { fail("export_params: nothing loaded"); return 0; }
+  if (dst) {
+    if (cap < r.blob.size()) { fail("export_params: destination too small"); return 0; }
+    std::memcpy(dst, r.blob.data(), r.blob.size());
+  }
+  return r.blob.size();
+}
+
+int bnn_mi355x_import_params(const void *src, size_t bytes) {
+  Runtime &r = rt();
+  const std::string e = validate_blob(r.spec, src, bytes);
+  if (!e.empty()) return fail(e);
+  r.blob.assign(static_cast<const uint8_t *>(src), static_cast<const uint8_t *>(src) + bytes);
+  if (upload_blob()) { r.blob.clear(); return -1; }
+  r.err.clear();
+  return 0;
+}
+
+int *bnn_mi355x_inference_buffer(const uint8_t *images, int n_images, int number_class, float *usecPerImage,
+                                 int enable_detail) {
+  if (!ready()) return nullptr;
+  if (n_images < 0 || (n_images > 0 && !images)) { fail("inference_buffer: bad arguments"); return nullptr; }
+  return classify_host(images, n_images, number_class, usecPerImage, enable_detail);
+}
+
+int bnn_mi355x_inference_raw(const uint8_t *images, int n_images, int16_t *scores, uint64_t *words,
+                             float *usecPerImage) {
+  if (!ready()) return -1;
+  if (n_images < 0 || (n_images > 0 && !images)) return fail("inference_raw: bad arguments");
+  return infer_host(images, n_images, 64, nullptr, scores, words, usecPerImage);
+}
+
+int bnn_mi355x_reserve(int max_images) { return ready() ? reserve(max_images) : -1; }
+
+int bnn_mi355x_profile(int enable) {
+  Runtime &r = rt();
+  r.profiling = enable != 0;
+  r.prof_used = 0;
+  return 0;
+}
+
+int bnn_mi355x_profile_read(float *ms_per_stage, int cap, int *n_chunks) {
+  Runtime &r = rt();
+  const int stages = r.spec.is_cnv ? kCnvStages : kLfcStages;
+  if (!ms_per_stage || cap < stages) return fail("profile_read: need room for all stages");
+  for (int i = 0; i < stages; i++) ms_per_stage[i] = 0.f;
+  for (size_t k = 0; k < r.prof_used; k++) {
+    std::vector<hipEvent_t> &set = r.prof_sets[k];
+    HIP_OK(hipEventSynchronize(set[stages]));
+    for (int i = 0; i < stages; i++) {
+      float ms = 0.f;
+      HIP_OK(hipEventElapsedTime(&ms, set[i], set[i + 1]));
+      ms_per_stage[i] += ms;
+    }
+  }
+  if (n_chunks) *n_chunks = (int)r.prof_used;
+  r.prof_used = 0;
+  return stages;
+}
+
+const char *bnn_mi355x_stage_name(int stage) { return stage_name(rt().spec.is_cnv, stage); }
+
+int bnn_mi355x_inference_device(const void *d_images, int n_images, int number_class, int32_t *d_classes,
+                                int16_t *d_scores, uint64_t *d_words, void *hip_stream) {
+  Runtime &r = rt();
+  if (!ready()) return -1;
+  if (n_images < 0 || (n_images > 0 && !d_images)) return fail("inference_device: bad arguments");
+  if (number_class < 1 || number_class > 64) return fail("number_class must be in 1..64");
+  hipStream_t s = static_cast<hipStream_t>(hip_stream);
+  const size_t isz = (size_t)r.spec.image_bytes();
+  for (int base = 0; base < n_images; base += kMaxChunk) {
+    const int m = (n_images - base < kMaxChunk) ? n_images - base : kMaxChunk;
+    if (reserve(m)) return -1;
+    if (enqueue(static_cast<const uint8_t *>(d_images) + (size_t)base * isz, m, number_class,
+                d_classes ? d_classes + base : nullptr, d_scores ? d_scores + (size_t)base * 64 : nullptr,
+                d_words ? d_words + base : nullptr, s))
+      return -1;
+  }
+  return 0;
+}
+
+}  // extern "C"

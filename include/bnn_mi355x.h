@@ -1,0 +1,129 @@
+/*
+ * bnn_mi355x.h -- C ABI of the MI355X-native BNN-PYNQ runtime.
+ *
+ * One shared object per network, named like the reference's build does
+ * (bnn/src/network/make-sw.sh:106-119):
+ *     <runtime>-<network>-<platform>.so      e.g. python_sw-cnvW1A1-mi355x.so
+ * It drops into bnn/libraries/<platform>/ and is dlopen'ed by the reference's
+ * cffi shim (bnn/bnn.py:67-79,108-111) unchanged.
+ *
+ * PART 1 is exactly the reference's cdef (bnn/bnn.py:69-77); the functions
+ * they replace are the extern "C" entry points of
+ * bnn/src/network/<net>/sw/main_python.cpp.  PART 2 are extensions for
+ * callers that already hold images in memory (host or HBM) and for multi-GPU
+ * parameter broadcast; they use plain pointers and sizes only.
+ *
+ * Error behaviour: the reference throws C++ string literals across the ABI
+ * (=> std::terminate).  This library never throws: it prints the same text to
+ * stderr and returns NULL / -1 (a behavioural superset).
+ * Thread-safety: like the reference, one classifier per loaded .so, calls must
+ * not overlap (file-static weights: top.cpp:51-68, rawhls-offload.cpp:52).
+ */
+#ifndef BNN_MI355X_H
+#define BNN_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ PART 1 */
+
+/* Replaces load_parameters (cnvW1A1/sw/main_python.cpp:67-82,
+ * lfcW1A1/sw/main_python.cpp:65-75): reads <path>/L-P-weights.bin and
+ * L-P-thres.bin (format unchanged), repacks once, uploads to HBM. */
+void load_parameters(const char *path);
+
+/* Replaces inference (main_python.cpp:120-139 / lfc 113-133).  `path` is a
+ * CIFAR-10 binary file (records of 1+3072 bytes) or an MNIST idx3 file; only
+ * the first image is classified.  CNV: results (may be NULL) receives
+ * number_class 16-bit scores, return = first maximum.  LFC: results receives a
+ * 64-entry one-hot vector at round(log2(output word)), return = that index.
+ * usecPerImage (may be NULL): device compute time, inputs resident in HBM. */
+int inference(const char *path, int results[64], int number_class, float *usecPerImage);
+
+/* Replaces inference_multiple (main_python.cpp:141-169 / lfc 135-156).
+ * Returns a new int[n] of class indices (CNV: first strict maximum floored at
+ * 0, foldedmv-offload.h:396-408; LFC: floor(log2(word)), foldedmv-offload.cpp:
+ * 202-220) or, CNV with enable_detail != 0, a new int[n*number_class] of
+ * scores.  No 10 000-image cap (the reference's INPUT_BUF_ENTRIES limit,
+ * foldedmv-offload.h:56-58): the batch is chunked internally.
+ * Free with free_results(). */
+int *inference_multiple(const char *path, int number_class, int *image_number, float *usecPerImage,
+                        int enable_detail);
+
+/* Replaces inference_multiple_with_faults (main_python.cpp:171-223).
+ * flip_count == 0: classifies like inference_multiple(enable_detail = 0).
+ * flip_count > 0: not available (the reference draws fault positions from
+ * std::random_device, faults.h:115-148); prints a message and returns NULL. */
+int *inference_multiple_with_faults(const char *path, int number_class, int *image_number,
+                                    float *usecPerImage, unsigned int flip_count, int word_size,
+                                    int target, int *target_layers, unsigned int num_targets);
+
+/* Replaces free_results (main_python.cpp:225-227). */
+void free_results(int *result);
+
+/* Replaces deinit (main_python.cpp:229-231, FoldedMVDeinit): frees the I/O
+ * workspace; the loaded parameters stay, as in the reference. */
+void deinit(void);
+
+/* ------------------------------------------------------------------ PART 2 */
+
+/* network compiled into this .so ("cnvW1A1", ...), and bytes per input image
+ * (3072 planar CHW uint8 for cnv*, 784 for lfc*) */
+const char *bnn_mi355x_network(void);
+int bnn_mi355x_image_bytes(void);
+
+/* last error text of this library ("" if none) */
+const char *bnn_mi355x_last_error(void);
+
+/* select the GPU (HIP ordinal) used by this library instance; call before
+ * load_parameters.  Returns 0 on success. */
+int bnn_mi355x_set_device(int ordinal);
+
+/* Packed parameter blob (position-independent bytes, see csrc/packed_params.h).
+ * pack: param directory -> blob, host only, touches no GPU (dst may be NULL to
+ *       query the size); returns bytes or 0 on error.
+ * export: the blob currently loaded; import: upload a blob obtained elsewhere,
+ *       e.g. received through an RCCL broadcast from rank 0. */
+size_t bnn_mi355x_pack_params(const char *path, void *dst, size_t cap);
+size_t bnn_mi355x_export_params(void *dst, size_t cap);
+int bnn_mi355x_import_params(const void *src, size_t bytes);
+
+/* Classify n images held in HOST memory (n x image_bytes, same byte layout as
+ * the bodies of the file formats).  Same return convention and ownership as
+ * inference_multiple. */
+int *bnn_mi355x_inference_buffer(const uint8_t *images, int n_images, int number_class,
+                                 float *usecPerImage, int enable_detail);
+
+/* Raw outputs for n host images: CNV scores[n*64] (16-bit, all 64 neurons of
+ * layer 8), LFC words[n] (raw 64-bit output word).  Either may be NULL.
+ * Returns 0 on success. */
+int bnn_mi355x_inference_raw(const uint8_t *images, int n_images, int16_t *scores, uint64_t *words,
+                             float *usecPerImage);
+
+/* Classify n images already resident in HBM, asynchronously on `hip_stream`
+ * (a hipStream_t, NULL = the default stream).  d_classes: int32[n] (batched
+ * decode); d_scores (CNV, optional): int16[n*64]; d_words (LFC, optional):
+ * uint64[n].  All device pointers.  The workspace grows on demand (which
+ * synchronises); call bnn_mi355x_reserve first to keep the call fully
+ * asynchronous / graph-capturable.  Returns 0 on success. */
+int bnn_mi355x_inference_device(const void *d_images, int n_images, int number_class, int32_t *d_classes,
+                                int16_t *d_scores, uint64_t *d_words, void *hip_stream);
+int bnn_mi355x_reserve(int max_images);
+
+/* Per-stage device timing with HIP events on the stream the kernels run on
+ * (used by bench.py for the roofline line).  profile(1) makes every later
+ * inference call bracket each stage with events; profile_read waits for them,
+ * writes the SUM of each stage's milliseconds over all chunks enqueued since
+ * the last read (n_chunks of them) and returns the number of stages, or -1. */
+int bnn_mi355x_profile(int enable);
+int bnn_mi355x_profile_read(float *ms_per_stage, int cap, int *n_chunks);
+const char *bnn_mi355x_stage_name(int stage);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

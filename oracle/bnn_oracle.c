@@ -152,11 +152,15 @@ static int read_words(const char *path, uint64_t *dst, size_t n) {
   memset(dst, 0, n * sizeof(uint64_t));
   for (size_t i = 0; i < n; i++) {
     unsigned char b[8];
+    memset(b, 0, 8);
     size_t got = fread(b, 1, 8, f);
-    if (got != 8) break; /* e stays 0 (foldedmv-offload.cpp:283-284) */
+    /* `ExtMemWord e = 0; wf.read((char*)&e, 8)` (foldedmv-offload.cpp:283-284):
+     * a short read stores the bytes it got and sets failbit, every later word
+     * stays 0 */
     uint64_t e = 0;
     for (int k = 7; k >= 0; k--) e = (e << 8) | b[k];
     dst[i] = e;
+    if (got != 8) break;
   }
   fclose(f);
   return 0;

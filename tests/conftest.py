@@ -3,6 +3,14 @@ import sys
 
 import pytest
 
+# torch (device memory / torch.distributed plumbing) bundles its own HIP runtime with the same
+# SONAME as /opt/rocm's: import it BEFORE the product library is dlopen'ed so that the process
+# holds exactly one HIP runtime ("One HIP runtime per process").
+try:
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "bnn-pynq_amd"))

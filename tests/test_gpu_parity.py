@@ -1,0 +1,200 @@
+"""GPU parity tests proper: the HIP path (through the C ABI of
+include/bnn_mi355x.h) against the CPU restatement (oracle/) on the same seeded
+inputs, bit-exact on the RAW outputs (all 64 16-bit scores per CNV image, the
+full 64-bit word per LFC image), not only on the argmax."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import gpu_lib as gl
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+NETS = [("cnvW1A1", "cifar10"), ("cnvW1A2", "cifar10"), ("cnvW2A2", "cifar10"),
+        ("lfcW1A1", "mnist"), ("lfcW1A2", "mnist"),
+        ("cnvW1A1", "streetview"), ("cnvW1A1", "road-signs"), ("lfcW1A1", "chars_merged")]
+
+_nets, _oracles = {}, {}
+
+
+def gpu_net(network, dataset):
+    # one .so holds one parameter set at a time (like the reference): reload on switch
+    key = (network, dataset)
+    if _nets.get(network, (None, None))[0] != dataset:
+        _nets[network] = (dataset, gl.Net(network, dataset))
+    return _nets[network][1]
+
+
+def oracle(network, dataset):
+    key = (network, dataset)
+    if key not in _oracles:
+        _oracles[key] = ol.Oracle(network, ol.param_dir(dataset, network))
+    return _oracles[key]
+
+
+def rand_images(network, n, seed, kind="uniform"):
+    rng = np.random.default_rng(seed)
+    isz = 3072 if network.startswith("cnv") else 784
+    if kind == "uniform":
+        return rng.integers(0, 256, size=(n, isz), dtype=np.uint8)
+    if kind == "sparse":  # MNIST-like: 10 % bright pixels
+        return np.where(rng.random((n, isz)) < 0.1, 255, 0).astype(np.uint8)
+    if kind == "edges":  # quantiser edge values
+        return rng.choice(np.array([0, 1, 126, 127, 128, 129, 254, 255], np.uint8), size=(n, isz))
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("network,dataset", NETS, ids=lambda x: x)
+@pytest.mark.parametrize("kind", ["uniform", "sparse", "edges"])
+def test_raw_outputs_bit_exact(network, dataset, kind):
+    n = 333 if network.startswith("cnv") else 2000  # ragged: not a multiple of the 256-lane blocks
+    imgs = rand_images(network, n, 7, kind)
+    g = gpu_net(network, dataset).raw(imgs)
+    o = oracle(network, dataset)
+    ref = o.scores_fast(imgs) if o.is_cnv else o.words_fast(imgs)
+    assert g.shape == ref.shape
+    bad = np.nonzero((g != ref).reshape(n, -1).any(axis=1))[0]
+    assert bad.size == 0, "first mismatching images: %s" % bad[:8]
+
+
+@pytest.mark.parametrize("network,dataset", NETS[:5], ids=lambda x: x)
+def test_gpu_matches_faithful_scalar_oracle(network, dataset):
+    """a few images against the one-MAC-at-a-time restatement (not the popcount one)"""
+    imgs = rand_images(network, 3, 11)
+    g = gpu_net(network, dataset).raw(imgs)
+    o = oracle(network, dataset)
+    for i in range(3):
+        if o.is_cnv:
+            assert g[i].tolist() == o.scores_ref(imgs[i]).tolist()
+        else:
+            assert int(g[i]) == o.word_ref(imgs[i])
+
+
+@pytest.mark.parametrize("network,dataset", NETS, ids=lambda x: x)
+def test_batched_classes(network, dataset):
+    ncls = ol.num_classes(dataset, network)
+    n = 1000
+    imgs = rand_images(network, n, 5)
+    got = gpu_net(network, dataset).classify(imgs, ncls)
+    want = oracle(network, dataset).classes_batched(imgs, ncls)
+    assert got.tolist() == want.tolist()
+
+
+def test_detail_scores():
+    ncls = 10
+    imgs = rand_images("cnvW1A1", 77, 3)
+    got = gpu_net("cnvW1A1", "cifar10").classify(imgs, ncls, detail=True).reshape(77, ncls)
+    want = oracle("cnvW1A1", "cifar10").scores_fast(imgs)[:, :ncls]
+    assert (got == want).all()
+
+
+def test_empty_and_single():
+    net = gpu_net("cnvW1A1", "cifar10")
+    assert net.classify(np.zeros((0, 3072), np.uint8), 10).size == 0
+    one = rand_images("cnvW1A1", 1, 1)
+    assert net.raw(one)[0].tolist() == oracle("cnvW1A1", "cifar10").scores_ref(one[0]).tolist()
+
+
+EXP = json.load(open(os.path.join(ol.GOLDEN, "expected.json")))
+
+
+@pytest.mark.parametrize("e", EXP["scores"], ids=lambda e: e["input"] + "-" + e["network"])
+def test_recorded_scores_through_file_abi(e):
+    """the reference's recorded score vectors, through inference(path, results, ...)"""
+    net = gpu_net(e["network"], e["params"])
+    res = (C.c_int * 64)()
+    usec = C.c_float(0)
+    cls = net.L.inference(os.path.join(ol.GOLDEN, e["input"]).encode(), res, 10, C.byref(usec))
+    assert list(res[:10]) == e["scores"], e["source"]
+    assert cls == int(np.argmax(e["scores"]))
+    assert usec.value > 0
+
+
+@pytest.mark.parametrize("e", EXP["classes"], ids=lambda e: e["input"] + "-" + e["network"] + "-" + e["params"])
+def test_recorded_classes_through_file_abi(e):
+    net = gpu_net(e["network"], e["params"])
+    ncls = ol.num_classes(e["params"], e["network"])
+    path = os.path.join(ol.GOLDEN, e["input"]).encode()
+    assert net.L.inference(path, None, ncls, None) == e["class"], e["source"]
+    n = C.c_int(0)
+    usec = C.c_float(0)
+    p = net.L.inference_multiple(path, ncls, C.byref(n), C.byref(usec), 0)
+    assert n.value == 1 and p[0] == e["class"], e["source"]
+    net.L.free_results(p)
+
+
+def test_lfc_single_one_hot():
+    net = gpu_net("lfcW1A1", "mnist")
+    res = (C.c_int * 64)()
+    cls = net.L.inference(os.path.join(ol.GOLDEN, "3.image-idx3-ubyte").encode(), res, 10, None)
+    assert cls == 3 and list(res) == [1 if i == 3 else 0 for i in range(64)]
+
+
+def test_full_size_batch_properties():
+    """BASELINE-size batch (10 000 CIFAR images): oracle on a seeded sample, plus
+    size-independent properties -- batch-order equivariance and chunk independence."""
+    n = 10000
+    imgs = rand_images("cnvW1A1", n, 1)
+    net = gpu_net("cnvW1A1", "cifar10")
+    s = net.raw(imgs)
+    perm = np.random.default_rng(0).permutation(n)
+    assert (net.raw(imgs[perm]) == s[perm]).all()
+    pick = np.random.default_rng(1).choice(n, 400, replace=False)
+    assert (oracle("cnvW1A1", "cifar10").scores_fast(imgs[pick]) == s[pick]).all()
+    # the same image repeated gives the same scores wherever it sits in the batch
+    rep = np.repeat(imgs[:1], 700, axis=0)
+    assert (net.raw(rep) == s[0]).all()
+
+
+def test_lfc_full_size_batch():
+    n = 10000
+    for network in ("lfcW1A1", "lfcW1A2"):
+        imgs = rand_images(network, n, 0)
+        got = gpu_net(network, "mnist").raw(imgs)
+        assert (got == oracle(network, "mnist").words_fast(imgs)).all()
+
+
+def test_device_api_and_blob_roundtrip():
+    """images resident in HBM (torch is only the allocator here) + export/import of the packed blob"""
+    import torch
+    net = gpu_net("cnvW1A1", "cifar10")
+    n = 5000
+    imgs = rand_images("cnvW1A1", n, 9)
+    d = torch.from_numpy(imgs).cuda()
+    cls = torch.zeros(n, dtype=torch.int32, device="cuda")
+    sc = torch.zeros(n, 64, dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    st = torch.cuda.current_stream().cuda_stream
+    assert net.L.bnn_mi355x_inference_device(d.data_ptr(), n, 10, cls.data_ptr(), sc.data_ptr(), None, st) == 0
+    torch.cuda.synchronize()
+    o = oracle("cnvW1A1", "cifar10")
+    want = o.scores_fast(imgs)
+    assert (sc.cpu().numpy() == want).all()
+    assert cls.cpu().numpy().tolist() == o.classes_batched(imgs, 10).tolist()
+    # blob export -> import gives the same network
+    size = net.L.bnn_mi355x_export_params(None, 0)
+    blob = np.zeros(size, np.uint8)
+    assert net.L.bnn_mi355x_export_params(blob.ctypes.data, size) == size
+    assert (blob == gl.pack_params("cnvW1A1", gl.param_dir("cifar10", "cnvW1A1"))).all()
+    assert net.L.bnn_mi355x_import_params(blob.ctypes.data, size) == 0
+    assert (net.raw(imgs[:64]) == want[:64]).all()
+
+
+def test_lfc_device_decode():
+    import torch
+    net = gpu_net("lfcW1A1", "mnist")
+    n = 3000
+    imgs = rand_images("lfcW1A1", n, 4, "sparse")
+    d = torch.from_numpy(imgs).cuda()
+    cls = torch.zeros(n, dtype=torch.int32, device="cuda")
+    words = torch.zeros(n, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    assert net.L.bnn_mi355x_inference_device(d.data_ptr(), n, 10, cls.data_ptr(), None, words.data_ptr(), None) == 0
+    torch.cuda.synchronize()
+    o = oracle("lfcW1A1", "mnist")
+    assert (words.cpu().numpy().view(np.uint64) == o.words_fast(imgs)).all()
+    assert cls.cpu().numpy().tolist() == o.classes_batched(imgs, 10).tolist()

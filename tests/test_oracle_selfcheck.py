@@ -1,0 +1,82 @@
+"""CPU: internal consistency of the oracle: popcount/OpenMP path == faithful
+scalar path, input conversion closed forms, decode quirks, file parsers."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+SETS = [("cnvW1A1", "cifar10"), ("cnvW1A2", "cifar10"), ("cnvW2A2", "cifar10"), ("lfcW1A1", "mnist"),
+        ("lfcW1A2", "mnist")]
+
+
+@pytest.mark.parametrize("network,dataset", SETS, ids=lambda x: x)
+def test_fast_equals_faithful(network, dataset):
+    o = ol.Oracle(network, ol.param_dir(dataset, network))
+    rng = np.random.default_rng(3)
+    if o.is_cnv:
+        imgs = rng.integers(0, 256, (4, 3072), dtype=np.uint8)
+        fast = o.scores_fast(imgs)
+        for i in range(4):
+            assert fast[i].tolist() == o.scores_ref(imgs[i]).tolist()
+    else:
+        imgs = rng.integers(0, 256, (200, 784), dtype=np.uint8)
+        fast = o.words_fast(imgs, nthreads=2)
+        assert [int(x) for x in fast] == [o.word_ref(imgs[i]) for i in range(200)]
+
+
+def test_quantiser_closed_form():
+    """int8 q = clamp(floor(256p/255 - 128 + .5)) == p - 128 + (p >= 128) - (p == 255) (the GPU's SWAR form)"""
+    L = ol.lib()
+    for p in range(256):
+        q = L.bnn_oracle_quantise_u8(p)
+        assert q == p - 128 + (p >= 128) - (p == 255)
+        assert q == max(-128, min(127, int(np.floor(256.0 * p / 255.0 - 128 + 0.5))))
+        assert q != 0
+
+
+def test_decode_quirks():
+    L = ol.lib()
+    s = np.zeros(64, np.int16)
+    s[:10] = [-5, -3, -9, -1, -2, -7, -8, -4, -6, -10]
+    assert ol.decode_cnv_batched(s, 10) == 0      # all <= 0: floored at 0 -> class 0
+    assert ol.decode_cnv_single(s, 10) == 3       # true first maximum
+    s[:10] = [1, 7, 7, 2, 0, 0, 0, 0, 0, 0]
+    assert ol.decode_cnv_batched(s, 10) == 1 and ol.decode_cnv_single(s, 10) == 1  # first of equal maxima
+    assert L.bnn_oracle_decode_lfc_batched(0b1100, 10) == 3   # floor(log2(12))
+    assert L.bnn_oracle_decode_lfc_single(0b1100, 10) == 4    # round(log2(12)) = round(3.58)
+    assert L.bnn_oracle_decode_lfc_batched(0, 10) == 0 and L.bnn_oracle_decode_lfc_single(0, 10) == 0
+    assert L.bnn_oracle_decode_lfc_batched(0b1_00000_00001, 10) == 0  # bit 10 masked off, bit 0 left
+    for k in range(47):  # exact below 2^47: where the GPU decodes with clz
+        w = (1 << (k + 1)) - 1
+        assert L.bnn_oracle_decode_lfc_batched(w, 64) == k
+
+
+def test_parsers(tmp_path):
+    import ctypes as C
+    L = ol.lib()
+    rng = np.random.default_rng(0)
+    recs = rng.integers(0, 256, (5, 3073), dtype=np.uint8)
+    p = tmp_path / "x.bin"
+    recs.tofile(p)
+    buf = C.POINTER(C.c_uint8)()
+    assert L.bnn_oracle_parse_cifar10(str(p).encode(), C.byref(buf)) == 5
+    got = np.ctypeslib.as_array(buf, shape=(5 * 3072,)).reshape(5, 3072).copy()
+    L.bnn_oracle_free(buf)
+    assert (got == recs[:, 1:]).all()
+    m = ol.read_mnist(os.path.join(ol.GOLDEN, "3.image-idx3-ubyte"))
+    assert m.shape == (1, 784)
+    assert L.bnn_oracle_parse_mnist(os.path.join(ol.GOLDEN, "3.image-idx3-ubyte").encode(), C.byref(buf)) == 1
+    assert (np.ctypeslib.as_array(buf, shape=(784,)) == m[0]).all()
+    L.bnn_oracle_free(buf)
+    assert L.bnn_oracle_parse_mnist(str(p).encode(), C.byref(buf)) == -1   # not an idx3 file
+
+
+def test_short_param_files_are_zero_filled():
+    """streetview/cnvW1A1 layer-8 files hold 1536 of 8192 words, chars_merged/lfcW1A1
+    layer 3 holds 384 of 512: loads, and the missing words read as 0 (= -1 weights)"""
+    o = ol.Oracle("cnvW1A1", ol.param_dir("streetview", "cnvW1A1"))
+    W = o.weights(8)
+    assert W.shape == (64, 512)
+    assert (W[12:] == -1).all() and (W[:12] != -1).any()

@@ -1,0 +1,110 @@
+"""CPU: the host-side repacker of the product (csrc/packed_params.cpp, reached
+through bnn_mi355x_pack_params -- pure host code) against the oracle's unpacked
+weights/thresholds for every layer of every shipped parameter set."""
+import struct
+
+import numpy as np
+import pytest
+
+import gpu_lib as gl
+import oracle_lib as ol
+
+SETS = [("cnvW1A1", "cifar10"), ("cnvW1A2", "cifar10"), ("cnvW2A2", "cifar10"), ("lfcW1A1", "mnist"),
+        ("lfcW1A2", "mnist"), ("cnvW1A1", "streetview"), ("cnvW1A1", "road-signs"), ("lfcW1A1", "chars_merged")]
+AR_INT8, AR_XNOR, AR_TB, AR_TT = 0, 1, 2, 3
+
+
+def arith_of(network, layer):
+    cnv = network.startswith("cnv")
+    if cnv and layer == 0:
+        return AR_INT8
+    if network.endswith("A1"):
+        return AR_XNOR
+    if network == "lfcW1A2" and layer == 0:
+        return AR_XNOR
+    return AR_TT if "W2" in network else AR_TB
+
+
+def bits(words):
+    """u64 array [rows, kw] -> 0/1 array [rows, kw*64], LSB first"""
+    b = np.unpackbits(words.view(np.uint8).reshape(words.shape[0], -1), axis=1, bitorder="little")
+    return b.astype(np.int8)
+
+
+@pytest.mark.parametrize("network,dataset", SETS, ids=lambda x: x)
+def test_blob_matches_oracle_weights(network, dataset):
+    blob = gl.pack_params(network, gl.param_dir(dataset, network))
+    o = ol.Oracle(network, ol.param_dir(dataset, network))
+    magic0, magic1, version, net_id, nlayers, total, _, _ = struct.unpack_from("<8I", blob, 0)
+    assert (magic0, magic1, version) == (0x4D4E4E42, 0x35353349, 1)
+    assert total == blob.size and nlayers == o.nl
+    for l in range(nlayers):
+        off, rd, rows, kw = struct.unpack_from("<4I", blob, 32 + 16 * l)
+        assert off % 256 == 0
+        W = o.weights(l)
+        mh, mw = W.shape
+        assert rows == mh
+        R = blob[off:off + rows * rd * 4].view(np.uint32).reshape(rows, rd)
+        ar = arith_of(network, l)
+        if ar == AR_INT8:
+            assert rd == 12 and kw == 0
+            by = R[:, 2:11].copy().view(np.int8).reshape(rows, 3, 3, 4)  # [n][c][ky][kx(+pad)]
+            assert (by[..., 3] == 0).all()
+            want = W.reshape(rows, 3, 3, 3).transpose(0, 3, 1, 2)  # [n][ky][kx][c] -> [n][c][ky][kx]
+            assert (by[..., :3] == want).all()
+        else:
+            assert kw == mw // 64
+            wq = R[:, 2:].copy().view(np.uint64)
+            if ar == AR_XNOR:
+                assert (bits(wq) == (W > 0)).all()
+            elif ar == AR_TB:
+                assert (W != 0).all() and (bits(wq) == (W < 0)).all()
+            else:
+                assert (bits(np.ascontiguousarray(wq[:, 0::2])) == (W < 0)).all()
+                assert (bits(np.ascontiguousarray(wq[:, 1::2])) == (W != 0)).all()
+        # thresholds: check the pre-transformed form against its definition
+        L = o.L
+        t = R[:, :2].astype(np.uint32).view(np.int32)
+        last_cnv = network.startswith("cnv") and l == 8
+        if last_cnv:
+            continue
+        nthr = 2 if (network.endswith("A2") and not (network == "lfcW1A2" and l == 3)) else 1
+        for n in range(0, mh, max(1, mh // 37)):
+            for i in range(nthr):
+                T = L.bnn_oracle_threshold(o.h, l, n, i)
+                if ar == AR_INT8:
+                    want_t = T >> 1
+                elif ar == AR_XNOR and network == "lfcW1A2":
+                    want_t = (mw - T + 1) >> 1
+                elif ar == AR_XNOR:
+                    want_t = mw - T
+                else:
+                    want_t = T
+                assert t[n, i] == want_t
+            if nthr == 1:
+                assert t[n, 1] == t[n, 0]
+
+
+def test_threshold_transforms_are_equivalences():
+    """the three pre-transformed compares used by the kernels are exact rewrites
+    of the reference's strict `T < acc` over the whole reachable range"""
+    rng = np.random.default_rng(0)
+    # XNOR: T < MW - m  <=>  m < MW - T
+    for MW in (576, 832, 1152, 2304):
+        m = rng.integers(0, MW + 1, 20000)
+        T = rng.integers(-32768, 32768, 20000)
+        assert ((T < MW - m) == (m < MW - T)).all()
+        # signed form: T < MW - 2m  <=>  m < floor((MW - T + 1) / 2)
+        assert ((T < MW - 2 * m) == (m < ((MW - T + 1) >> 1))).all()
+    # layer 0: T < 2*dot  <=>  floor(T/2) < dot
+    d = rng.integers(-3456, 3457, 50000)
+    T = rng.integers(-2 ** 23, 2 ** 23, 50000)
+    assert ((T < 2 * d) == ((T >> 1) < d)).all()
+    T = rng.integers(-7000, 7000, 50000)
+    assert ((T < 2 * d) == ((T >> 1) < d)).all()
+
+
+def test_missing_file_is_reported():
+    L = gl.load("cnvW1A1")
+    assert L.bnn_mi355x_pack_params(b"/nonexistent/dir", None, 0) == 0
+    assert b"Could not open file" in L.bnn_mi355x_last_error()
