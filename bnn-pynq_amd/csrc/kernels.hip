@@ -123,9 +123,9 @@ __device__ __forceinline__ int pool2(int a, int b) {
 // -> 30x30x64 thresholded map.
 // Replaces: chaninterleave + quantiseAndPack<8,1> (foldedmv-offload.h:129-144,
 // 381-386), the 64->192->24 width converters and ConvLayer_Batch<L0..>
-// (top.cpp:210-214).  One lane = one output pixel; the 27 int8 taps live in 9
-// dwords (3 taps of one (channel,row) + one don't-care byte whose weight byte
-// is 0) and each neuron costs 9 v_dot4c_i32_i8 against SGPR weight dwords.
+// (top.cpp:210-214).  One lane = one output pixel; the 27 int8 taps are gathered
+// as 9 x 3 bytes, compacted into 7 dwords with v_perm_b32, and each neuron
+// costs 7 v_dot4 against SGPR weight dwords + a subtract + a v_alignbit.
 // ---------------------------------------------------------------------------
 // uint8 p -> int8 q = clamp(floor(256*p/255 - 128 + 0.5)) = p - 128 + (p >= 128) - (p == 255),
 // four bytes at a time (no carry can cross a byte: see DESIGN.md).
@@ -134,6 +134,14 @@ __device__ __forceinline__ uint32_t quantise4(uint32_t p) {
   const uint32_t hi = (p >> 7) & 0x01010101u;                 // p >= 128
   const uint32_t f = (((t & 0x7F7F7F7Fu) + 0x01010101u) >> 7) & hi;  // p == 255
   return t + (hi ^ f);
+}
+
+// bits = (bits << 1) | (v < 0)
+// (the empty asm hides v's origin: otherwise LLVM turns "sign of a difference" back into
+// v_cmp + v_cndmask + v_lshl_or, three integer-pipe slots instead of one)
+__device__ __forceinline__ uint32_t shift_in_sign(uint32_t bits, int v) {
+  asm("" : "+v"(v));
+  return __builtin_amdgcn_alignbit(bits, (uint32_t)v, 31);
 }
 
 template <bool OUT2>
@@ -145,7 +153,8 @@ __global__ __launch_bounds__(kBlock) void k_conv0(const uint8_t *__restrict__ im
   const int oy = p / 30, ox = p - oy * 30;
   const uint32_t *__restrict__ im32 = reinterpret_cast<const uint32_t *>(imgs + (size_t)img * 3072);
   const int sh = ox & 3;
-  uint32_t a[9];
+  // g[c*3+r] = bytes {x, x+1, x+2, don't-care} of channel c, row oy+r
+  uint32_t g[9];
 #pragma unroll
   for (int c = 0; c < 3; c++)
 #pragma unroll
@@ -153,17 +162,37 @@ __global__ __launch_bounds__(kBlock) void k_conv0(const uint8_t *__restrict__ im
       const int idx = c * 256 + (oy + r) * 8 + (ox >> 2);
       const uint32_t d0 = im32[idx];
       const uint32_t d1 = im32[idx + 1 < 768 ? idx + 1 : 767];  // only ever feeds the don't-care byte when clamped
-      a[c * 3 + r] = quantise4(__builtin_amdgcn_alignbyte(d1, d0, sh));
+      g[c * 3 + r] = __builtin_amdgcn_alignbyte(d1, d0, sh);
     }
+  // compact the 27 taps into 7 dwords (tap 3*grp + kx at byte (3*grp+kx)%4 of dword (3*grp+kx)/4), then quantise
+  uint32_t a[7];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    a[3 * h + 0] = __builtin_amdgcn_perm(g[4 * h + 1], g[4 * h + 0], 0x04020100u);
+    a[3 * h + 1] = __builtin_amdgcn_perm(g[4 * h + 2], g[4 * h + 1], 0x05040201u);
+    a[3 * h + 2] = __builtin_amdgcn_perm(g[4 * h + 3], g[4 * h + 2], 0x06050402u);
+  }
+  a[6] = g[8];  // taps 24..26 + one don't-care byte (its weight byte is 0)
+#pragma unroll
+  for (int j = 0; j < 7; j++) a[j] = quantise4(a[j]);
   kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)blockIdx.y * 32 * 12);
   uint32_t b0 = 0, b1 = 0;
-  for (int c = 0; c < 32; c++) {
+  for (int c = 31; c >= 0; c--) {
     kptr32 r = w + c * 12;
     int acc = 0;
 #pragma unroll
-    for (int k = 0; k < 9; k++) acc = __builtin_amdgcn_sdot4((int)a[k], (int)r[2 + k], acc, false);
-    push_bits<OUT2>(b0, b1, (int)r[0] < acc, (int)r[1] < acc, 1u << c);
+    for (int k = 0; k < 7; k++) acc = __builtin_amdgcn_sdot4((int)a[k], (int)r[2 + k], acc, false);
+    // fire_i = t_i < acc  <=>  t_i - acc < 0: shift the sign bits in, channel c ends on bit c
+    const int d0 = (int)r[0] - acc;
+    if constexpr (!OUT2) {
+      b0 = shift_in_sign(b0, d0);
+    } else {
+      const int d1 = (int)r[1] - acc;
+      b0 = shift_in_sign(b0, d0 | d1);  // sign plane = !(f0 | f1): inverted below
+      b1 = shift_in_sign(b1, d0 ^ d1);  // non-zero plane = (f0 == f1): inverted below
+    }
   }
+  if constexpr (OUT2) { b0 = ~b0; b1 = ~b1; }
   store_bits<OUT2>(out, (size_t)item, 2, blockIdx.y, b0, b1);
 }
 
@@ -314,6 +343,144 @@ __global__ __launch_bounds__(kBlock) void k_vec(const uint64_t *__restrict__ in,
   store_bits<OUT2>(out, (size_t)item, gridDim.y, blockIdx.y, b0, b1);
 }
 
+
+// ---------------------------------------------------------------------------
+// AR_XNOR, 1-bit out: the headline path (cnvW1A1 layers 1..7, lfcW1A1).
+// Measured on MI355X (profiles/r01_microbench*.txt): v_xor_b32 and
+// v_bcnt_u32_b32 both go down the integer pipe, ~4.2 cycles per wave64
+// instruction per SIMD for v_bcnt and for anything with an SGPR operand; an
+// alternating xor/bcnt stream sustains 6.6 cycles per 32-bit pair.  That pair
+// rate IS the roofline of this path, so the kernels below spend integer-pipe
+// slots on nothing else:
+//   * every accumulator is one chain of v_bcnt (which adds for free); the empty
+//     asm pins the chain so that LLVM does not re-associate it into a tree of
+//     v_add3_u32;
+//   * the threshold test is a subtract whose SIGN BIT is shifted into the
+//     result word with one v_alignbit_b32 (no v_cmp / v_cndmask / v_or);
+//     channels are walked 31..0 so that channel c lands on bit c.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void xpop(int &acc, uint32_t w, uint32_t a) {
+  acc = __builtin_popcount(w ^ a) + acc;
+  asm("" : "+v"(acc));
+}
+__device__ __forceinline__ int xpop0(uint32_t w, uint32_t a) {
+  int acc = __builtin_popcount(w ^ a);
+  asm("" : "+v"(acc));
+  return acc;
+}
+template <int CW, int ID, bool POOL>
+__global__ __launch_bounds__(kBlock) void k_quad_x(const uint64_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                    const uint32_t *__restrict__ rows, int n_items) {
+  constexpr int OD = ID - 2, QD = OD / 2, NQ = QD * QD, KW = 9 * CW, ROW_DW = 2 + 2 * KW;
+  const int item = blockIdx.x * kBlock + threadIdx.x;
+  if (item >= n_items) return;
+  const int img = item / NQ, q = item - img * NQ;
+  const int qy = q / QD, qx = q - qy * QD;
+  const uint64_t *__restrict__ base = in + ((size_t)img * ID * ID + (size_t)(2 * qy) * ID + 2 * qx) * CW;
+  uint32_t wl[4][4][CW], wh[4][4][CW];
+#pragma unroll
+  for (int y = 0; y < 4; y++)
+#pragma unroll
+    for (int x = 0; x < 4; x++)
+#pragma unroll
+      for (int k = 0; k < CW; k++) {
+        const uint64_t v = base[(y * ID + x) * CW + k];
+        wl[y][x][k] = (uint32_t)v;
+        wh[y][x][k] = (uint32_t)(v >> 32);
+      }
+  kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)blockIdx.y * 32 * ROW_DW);
+  uint32_t b[4] = {0, 0, 0, 0};
+  for (int c = 31; c >= 0; c--) {
+    kptr32 r = w + c * ROW_DW;
+    const int t = (int)r[0];
+    int m[2][2];
+#pragma unroll
+    for (int j = 0; j < KW; j++) {
+      const int ky = j / (3 * CW), kx = (j / CW) % 3, k = j % CW;
+      const uint32_t w0 = r[2 + 2 * j], w1 = r[3 + 2 * j];
+#pragma unroll
+      for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+        for (int dx = 0; dx < 2; dx++) {
+          if (j == 0) m[dy][dx] = xpop0(w0, wl[dy + ky][dx + kx][k]);
+          else xpop(m[dy][dx], w0, wl[dy + ky][dx + kx][k]);
+          xpop(m[dy][dx], w1, wh[dy + ky][dx + kx][k]);
+        }
+    }
+    if constexpr (POOL) {  // OR of the four fire bits == (min m) < t
+      const int mn = min(min(m[0][0], m[0][1]), min(m[1][0], m[1][1]));
+      b[0] = shift_in_sign(b[0], mn - t);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++) b[i] = shift_in_sign(b[i], m[i >> 1][i & 1] - t);
+    }
+  }
+  const int groups = gridDim.y;
+  if constexpr (POOL) {
+    out[(size_t)item * groups + blockIdx.y] = b[0];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const size_t pix = (size_t)img * OD * OD + (size_t)(2 * qy + (i >> 1)) * OD + 2 * qx + (i & 1);
+      out[pix * groups + blockIdx.y] = b[i];
+    }
+  }
+}
+
+// one lane = one vector of KW words (FC layers, CNV layer 5; SINGLE: CNV layer 4 window gather).
+// Two neurons per iteration: two independent v_bcnt chains per lane.
+template <int KW, bool SINGLE, int CW, int ID>
+__global__ __launch_bounds__(kBlock) void k_vec_x(const uint64_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                   const uint32_t *__restrict__ rows, int n_items) {
+  constexpr int ROW_DW = 2 + 2 * KW;
+  const int item = blockIdx.x * kBlock + threadIdx.x;
+  if (item >= n_items) return;
+  uint32_t al[KW], ah[KW];
+  if constexpr (SINGLE) {
+    constexpr int OD = ID - 2;
+    static_assert(KW == 9 * CW, "window size");
+    const int img = item / (OD * OD), p = item - img * (OD * OD);
+    const int oy = p / OD, ox = p - oy * OD;
+    const uint64_t *__restrict__ base = in + ((size_t)img * ID * ID + (size_t)oy * ID + ox) * CW;
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+        for (int k = 0; k < CW; k++) {
+          const uint64_t v = base[(ky * ID + kx) * CW + k];
+          al[(ky * 3 + kx) * CW + k] = (uint32_t)v;
+          ah[(ky * 3 + kx) * CW + k] = (uint32_t)(v >> 32);
+        }
+  } else {
+    const uint64_t *__restrict__ base = in + (size_t)item * KW;
+#pragma unroll
+    for (int k = 0; k < KW; k++) {
+      const uint64_t v = base[k];
+      al[k] = (uint32_t)v;
+      ah[k] = (uint32_t)(v >> 32);
+    }
+  }
+  kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)blockIdx.y * 32 * ROW_DW);
+  uint32_t b = 0;
+  for (int c = 31; c >= 0; c -= 2) {
+    kptr32 r1 = w + c * ROW_DW, r0 = r1 - ROW_DW;
+    int m1 = xpop0(r1[2], al[0]), m0 = xpop0(r0[2], al[0]);
+    xpop(m1, r1[3], ah[0]);
+    xpop(m0, r0[3], ah[0]);
+#pragma unroll
+    for (int k = 1; k < KW; k++) {
+      xpop(m1, r1[2 + 2 * k], al[k]);
+      xpop(m0, r0[2 + 2 * k], al[k]);
+      xpop(m1, r1[3 + 2 * k], ah[k]);
+      xpop(m0, r0[3 + 2 * k], ah[k]);
+    }
+    b = shift_in_sign(b, m1 - (int)r1[0]);
+    b = shift_in_sign(b, m0 - (int)r0[0]);
+  }
+  out[(size_t)item * gridDim.y + blockIdx.y] = b;
+}
+
 // ---------------------------------------------------------------------------
 // CNV layer 8: 512 -> 64 raw accumulators (PassThroughActivation<ap_uint<16>>,
 // top.cpp:232-235) + the batched class decode of
@@ -418,6 +585,22 @@ void run_cnv_t(const CnvLaunch &a) {
   BNN_MARK(a.events, 0, s);
   BNN_LAUNCH((k_conv0<OUT2>), grid_for(n * 900, 2), s, a.images, A, a.rows[0], (int)(n * 900));
   BNN_MARK(a.events, 1, s);
+  if constexpr (ARITH == AR_XNOR && !OUT2) {
+    BNN_LAUNCH((k_quad_x<1, 30, true>), grid_for(n * 196, 2), s, A64, B, a.rows[1], (int)(n * 196));
+    BNN_MARK(a.events, 2, s);
+    BNN_LAUNCH((k_quad_x<1, 14, false>), grid_for(n * 36, 4), s, B64, A, a.rows[2], (int)(n * 36));
+    BNN_MARK(a.events, 3, s);
+    BNN_LAUNCH((k_quad_x<2, 12, true>), grid_for(n * 25, 4), s, A64, B, a.rows[3], (int)(n * 25));
+    BNN_MARK(a.events, 4, s);
+    BNN_LAUNCH((k_vec_x<18, true, 2, 5>), grid_for(n * 9, 8), s, B64, A, a.rows[4], (int)(n * 9));
+    BNN_MARK(a.events, 5, s);
+    BNN_LAUNCH((k_vec_x<36, false, 1, 1>), grid_for(n, 8), s, A64, B, a.rows[5], (int)n);
+    BNN_MARK(a.events, 6, s);
+    BNN_LAUNCH((k_vec_x<4, false, 1, 1>), grid_for(n, 16), s, B64, A, a.rows[6], (int)n);
+    BNN_MARK(a.events, 7, s);
+    BNN_LAUNCH((k_vec_x<8, false, 1, 1>), grid_for(n, 16), s, A64, B, a.rows[7], (int)n);
+    BNN_MARK(a.events, 8, s);
+  } else {
   BNN_LAUNCH((k_quad<ARITH, 1, 30, true, OUT2>), grid_for(n * 196, 2), s, A64, B, a.rows[1], (int)(n * 196));
   BNN_MARK(a.events, 2, s);
   BNN_LAUNCH((k_quad<ARITH, 1, 14, false, OUT2>), grid_for(n * 36, 4), s, B64, A, a.rows[2], (int)(n * 36));
@@ -432,6 +615,7 @@ void run_cnv_t(const CnvLaunch &a) {
   BNN_MARK(a.events, 7, s);
   BNN_LAUNCH((k_vec<ARITH, 8, OUT2, false, 1, 1>), grid_for(n, 16), s, A64, B, a.rows[7], (int)n);
   BNN_MARK(a.events, 8, s);
+  }
   BNN_LAUNCH((k_fclast<ARITH, 8>), grid_for(n, 1), s, B64, a.scores, a.classes, a.rows[8], (int)n, a.number_class);
   BNN_MARK(a.events, 9, s);
 }
@@ -477,13 +661,13 @@ hipError_t run_lfc(NetId net, const LfcLaunch &a) {
   BNN_LAUNCH(k_lfc_binarize, grid_for(n * 13, 1), s, a.images, A64, (int)(n * 13));
   BNN_MARK(a.events, 1, s);
   if (net == NET_LFCW1A1) {
-    BNN_LAUNCH((k_vec<AR_XNOR, 13, false, false, 1, 1>), grid_for(n, 32), s, A64, B, a.rows[0], (int)n);
+    BNN_LAUNCH((k_vec_x<13, false, 1, 1>), grid_for(n, 32), s, A64, B, a.rows[0], (int)n);
     BNN_MARK(a.events, 2, s);
-    BNN_LAUNCH((k_vec<AR_XNOR, 16, false, false, 1, 1>), grid_for(n, 32), s, B64, A, a.rows[1], (int)n);
+    BNN_LAUNCH((k_vec_x<16, false, 1, 1>), grid_for(n, 32), s, B64, A, a.rows[1], (int)n);
     BNN_MARK(a.events, 3, s);
-    BNN_LAUNCH((k_vec<AR_XNOR, 16, false, false, 1, 1>), grid_for(n, 32), s, A64, B, a.rows[2], (int)n);
+    BNN_LAUNCH((k_vec_x<16, false, 1, 1>), grid_for(n, 32), s, A64, B, a.rows[2], (int)n);
     BNN_MARK(a.events, 4, s);
-    BNN_LAUNCH((k_vec<AR_XNOR, 16, false, false, 1, 1>), grid_for(n, 2), s, B64, reinterpret_cast<uint32_t *>(a.words), a.rows[3], (int)n);
+    BNN_LAUNCH((k_vec_x<16, false, 1, 1>), grid_for(n, 2), s, B64, reinterpret_cast<uint32_t *>(a.words), a.rows[3], (int)n);
     BNN_MARK(a.events, 5, s);
   } else if (net == NET_LFCW1A2) {
     BNN_LAUNCH((k_vec<AR_XNOR, 13, true, false, 1, 1>), grid_for(n, 32), s, A64, B, a.rows[0], (int)n);

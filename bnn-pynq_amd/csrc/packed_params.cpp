@@ -115,15 +115,14 @@ std::string pack_params_from_dir(const NetSpec &net, const std::string &dir, std
       row[1] = (uint32_t)t[1];
       // weights
       if (L.arith == AR_INT8) {
+        // tap tau = 3*(c*3+ky) + kx  <->  reference column (ky*3+kx)*3 + c
         for (int c = 0; c < 3; c++)
-          for (int ky = 0; ky < 3; ky++) {
-            uint32_t d = 0;
+          for (int ky = 0; ky < 3; ky++)
             for (int kx = 0; kx < 3; kx++) {
+              const int tau = 3 * (c * 3 + ky) + kx;
               const int wv = F.weight(n, (ky * 3 + kx) * 3 + c);
-              d |= (uint32_t)(uint8_t)(int8_t)wv << (8 * kx);
+              row[2 + tau / 4] |= (uint32_t)(uint8_t)(int8_t)wv << (8 * (tau % 4));
             }
-            row[2 + c * 3 + ky] = d;
-          }
       } else {
         uint64_t *wq = reinterpret_cast<uint64_t *>(row + 2);
         const int kw = MW / 64;

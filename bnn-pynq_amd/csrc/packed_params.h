@@ -17,8 +17,9 @@
 //   dword 0,1      t0, t1   pre-transformed thresholds (see below)
 //   dword 2..      the weight words of the row
 //
-//   AR_INT8   9 dwords, dword (c*3+ky) = bytes {w[ky][0][c], w[ky][1][c], w[ky][2][c], 0}
-//             as int8 in {-1,0,+1}; 1 pad dword.         fire_i = t_i < dot
+//   AR_INT8   7 dwords of int8 taps in {-1,0,+1}: tap tau = 3*(c*3+ky)+kx (channel-plane, row,
+//             then the 3 horizontally adjacent pixels) at byte tau%4 of dword tau/4, byte 27 = 0;
+//             3 pad dwords.                              fire_i = t_i < dot
 //             t_i = floor(T_i / 2)   (T in 2^-8 units, accumulator = 2*dot)
 //   AR_XNOR   KW x u64, bit j = 1 <=> weight +1.  m = popcount(w ^ a) = # mismatches
 //             fire_i = m < t_i,  t_i = MW - T_i           (T_i < MW - m)

@@ -48,10 +48,10 @@ def test_blob_matches_oracle_weights(network, dataset):
         ar = arith_of(network, l)
         if ar == AR_INT8:
             assert rd == 12 and kw == 0
-            by = R[:, 2:11].copy().view(np.int8).reshape(rows, 3, 3, 4)  # [n][c][ky][kx(+pad)]
-            assert (by[..., 3] == 0).all()
-            want = W.reshape(rows, 3, 3, 3).transpose(0, 3, 1, 2)  # [n][ky][kx][c] -> [n][c][ky][kx]
-            assert (by[..., :3] == want).all()
+            taps = R[:, 2:9].copy().view(np.int8).reshape(rows, 28)   # tap tau = 3*(c*3+ky)+kx
+            assert (taps[:, 27] == 0).all() and (R[:, 9:] == 0).all()
+            want = W.reshape(rows, 3, 3, 3).transpose(0, 3, 1, 2).reshape(rows, 27)  # [n][ky][kx][c] -> [n][c][ky][kx]
+            assert (taps[:, :27] == want).all()
         else:
             assert kw == mw // 64
             wq = R[:, 2:].copy().view(np.uint64)
