@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_DIR = os.path.join(ROOT, "bnn-pynq_amd", "bnn", "libraries", "mi355x")
+# BNN_MI355X_LIBDIR: kernel-tuning experiments point this at an alternative build of the same ABI
+LIB_DIR = os.environ.get("BNN_MI355X_LIBDIR") or os.path.join(ROOT, "bnn-pynq_amd", "bnn", "libraries", "mi355x")
 PARAM_ROOT = os.path.join(ROOT, "bnn-pynq_amd", "bnn", "params")
 
 LEGACY = ["load_parameters", "inference", "inference_multiple", "inference_multiple_with_faults",
