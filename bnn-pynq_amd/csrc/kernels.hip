@@ -210,154 +210,6 @@ __global__ __launch_bounds__(kBlock) void k_conv0(const uint8_t *__restrict__ im
 }
 
 // ---------------------------------------------------------------------------
-// 3x3 valid conv on bit-packed maps, one lane = a 2x2 quad of output pixels
-// (4x4 input window in VGPRs), optionally followed by the 2x2 max-pool.
-// Replaces ConvolutionInputGenerator + Matrix_Vector_Activate_Batch +
-// ThresholdsActivation (+ StreamingMaxPool_Batch) for CNV layers 1, 2, 3.
-// CW = 64-bit words per pixel per plane (Cin/64), ID = input map edge.
-// Every scalar weight word feeds 4 word-MACs (the 4 pixels of the quad).
-// ---------------------------------------------------------------------------
-template <int ARITH, int CW, int ID, bool POOL, bool OUT2>
-__global__ __launch_bounds__(kBlock) void k_quad(const uint64_t *__restrict__ in, uint32_t *__restrict__ out,
-                                                  const uint32_t *__restrict__ rows, int n_items) {
-  constexpr int OD = ID - 2, QD = OD / 2, NQ = QD * QD, PL = planes_in<ARITH>(), WPL = wplanes<ARITH>();
-  constexpr int KW = 9 * CW, ROW_DW = 2 + 2 * KW * WPL;
-  const int item = blockIdx.x * kBlock + threadIdx.x;
-  if (item >= n_items) return;
-  const int img = item / NQ, q = item - img * NQ;
-  const int qy = q / QD, qx = q - qy * QD;
-  const uint64_t *__restrict__ base = in + ((size_t)img * ID * ID + (size_t)(2 * qy) * ID + 2 * qx) * CW * PL;
-  uint64_t ws[4][4][CW], wz[4][4][PL == 2 ? CW : 1];
-#pragma unroll
-  for (int y = 0; y < 4; y++)
-#pragma unroll
-    for (int x = 0; x < 4; x++)
-#pragma unroll
-      for (int k = 0; k < CW; k++) {
-        ws[y][x][k] = base[((y * ID + x) * CW + k) * PL];
-        if constexpr (PL == 2) wz[y][x][k] = base[((y * ID + x) * CW + k) * PL + 1];
-      }
-  // AR_TB: # non-zero activations in each of the 4 windows (weight independent)
-  int nzt[2][2] = {{0, 0}, {0, 0}};
-  if constexpr (ARITH == AR_TB) {
-#pragma unroll
-    for (int dy = 0; dy < 2; dy++)
-#pragma unroll
-      for (int dx = 0; dx < 2; dx++)
-#pragma unroll
-        for (int ky = 0; ky < 3; ky++)
-#pragma unroll
-          for (int kx = 0; kx < 3; kx++)
-#pragma unroll
-            for (int k = 0; k < CW; k++) nzt[dy][dx] += pc64(wz[dy + ky][dx + kx][k]);
-  }
-  kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)blockIdx.y * 32 * ROW_DW);
-  uint32_t b0[4] = {0, 0, 0, 0}, b1[4] = {0, 0, 0, 0};
-  for (int c = 0; c < 32; c++) {
-    kptr32 r = w + c * ROW_DW;
-    kptr64 rw = (kptr64)(r + 2);
-    const int t0 = (int)r[0], t1 = (int)r[1];
-    int m[2][2] = {{0, 0}, {0, 0}}, z[2][2] = {{0, 0}, {0, 0}};
-#pragma unroll
-    for (int ky = 0; ky < 3; ky++)
-#pragma unroll
-      for (int kx = 0; kx < 3; kx++)
-#pragma unroll
-        for (int k = 0; k < CW; k++) {
-          kptr64 wk = rw + ((ky * 3 + kx) * CW + k) * WPL;
-#pragma unroll
-          for (int dy = 0; dy < 2; dy++)
-#pragma unroll
-            for (int dx = 0; dx < 2; dx++)
-              mac<ARITH>(m[dy][dx], z[dy][dx], ws[dy + ky][dx + kx][k], wz[dy + ky][dx + kx][PL == 2 ? k : 0], wk);
-        }
-    int v[2][2];
-#pragma unroll
-    for (int dy = 0; dy < 2; dy++)
-#pragma unroll
-      for (int dx = 0; dx < 2; dx++) v[dy][dx] = finish<ARITH>(m[dy][dx], z[dy][dx], nzt[dy][dx]);
-    if constexpr (POOL) {
-      const int p = pool2<ARITH>(pool2<ARITH>(v[0][0], v[0][1]), pool2<ARITH>(v[1][0], v[1][1]));
-      push_bits<OUT2>(b0[0], b1[0], fires<ARITH>(p, t0), fires<ARITH>(p, t1), 1u << c);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-        push_bits<OUT2>(b0[i], b1[i], fires<ARITH>(v[i >> 1][i & 1], t0), fires<ARITH>(v[i >> 1][i & 1], t1), 1u << c);
-    }
-  }
-  const int groups = gridDim.y;
-  if constexpr (POOL) {
-    store_bits<OUT2>(out, (size_t)item, groups, blockIdx.y, b0[0], b1[0]);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const size_t pix = (size_t)img * OD * OD + (size_t)(2 * qy + (i >> 1)) * OD + 2 * qx + (i & 1);
-      store_bits<OUT2>(out, pix, groups, blockIdx.y, b0[i], b1[i]);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// Generic "KW words in, thresholded bits out": one lane = one vector.
-//   * FC layers (StreamingFCLayer_Batch, top.cpp:228-231, lfc top.cpp:156-163):
-//     vector = image, KW = MW/64.
-//   * CNV layer 5 (3x3x256 -> 1x1x256): the window IS the whole map, already in
-//     (ky,kx,c) order in memory -> KW = 36.
-//   * CNV layer 4 (5x5x128 -> 3x3x256, SINGLE=true): vector = output pixel, its
-//     3x3 window gathered from the map (ID = 5, CW = 2 -> KW = 18).
-// ---------------------------------------------------------------------------
-template <int ARITH, int KW, bool OUT2, bool SINGLE, int CW, int ID>
-__global__ __launch_bounds__(kBlock) void k_vec(const uint64_t *__restrict__ in, uint32_t *__restrict__ out,
-                                                 const uint32_t *__restrict__ rows, int n_items) {
-  constexpr int PL = planes_in<ARITH>(), WPL = wplanes<ARITH>();
-  constexpr int ROW_DW = 2 + 2 * KW * WPL;
-  const int item = blockIdx.x * kBlock + threadIdx.x;
-  if (item >= n_items) return;
-  uint64_t as[KW], az[PL == 2 ? KW : 1];
-  if constexpr (SINGLE) {
-    constexpr int OD = ID - 2;
-    static_assert(KW == 9 * CW, "window size");
-    const int img = item / (OD * OD), p = item - img * (OD * OD);
-    const int oy = p / OD, ox = p - oy * OD;
-    const uint64_t *__restrict__ base = in + ((size_t)img * ID * ID + (size_t)oy * ID + ox) * CW * PL;
-#pragma unroll
-    for (int ky = 0; ky < 3; ky++)
-#pragma unroll
-      for (int kx = 0; kx < 3; kx++)
-#pragma unroll
-        for (int k = 0; k < CW; k++) {
-          as[(ky * 3 + kx) * CW + k] = base[((ky * ID + kx) * CW + k) * PL];
-          if constexpr (PL == 2) az[(ky * 3 + kx) * CW + k] = base[((ky * ID + kx) * CW + k) * PL + 1];
-        }
-  } else {
-    const uint64_t *__restrict__ base = in + (size_t)item * KW * PL;
-#pragma unroll
-    for (int k = 0; k < KW; k++) {
-      as[k] = base[k * PL];
-      if constexpr (PL == 2) az[k] = base[k * PL + 1];
-    }
-  }
-  int nzt = 0;
-  if constexpr (ARITH == AR_TB) {
-#pragma unroll
-    for (int k = 0; k < KW; k++) nzt += pc64(az[k]);
-  }
-  kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)blockIdx.y * 32 * ROW_DW);
-  uint32_t b0 = 0, b1 = 0;
-  for (int c = 0; c < 32; c++) {
-    kptr32 r = w + c * ROW_DW;
-    kptr64 rw = (kptr64)(r + 2);
-    int m = 0, z = 0;
-#pragma unroll
-    for (int k = 0; k < KW; k++) mac<ARITH>(m, z, as[k], az[PL == 2 ? k : 0], rw + k * WPL);
-    const int v = finish<ARITH>(m, z, nzt);
-    push_bits<OUT2>(b0, b1, fires<ARITH>(v, (int)r[0]), fires<ARITH>(v, (int)r[1]), 1u << c);
-  }
-  store_bits<OUT2>(out, (size_t)item, gridDim.y, blockIdx.y, b0, b1);
-}
-
-
-// ---------------------------------------------------------------------------
 // AR_XNOR, 1-bit out: the headline path (cnvW1A1 layers 1..7, lfcW1A1).
 // Measured on MI355X (profiles/r01_microbench*.txt): v_xor_b32 and
 // v_bcnt_u32_b32 both go down the integer pipe, ~4.2 cycles per wave64
@@ -509,6 +361,216 @@ __global__ __launch_bounds__(kBlock) void k_vec_x(const uint64_t *__restrict__ i
     b = shift_in_sign(b, m0 - (int)r0[0]);
   }
   out[(size_t)item * gridDim.y + blockIdx.y] = b;
+}
+
+
+// ---------------------------------------------------------------------------
+// Generic stages: the 2-bit-activation networks (cnvW1A2, cnvW2A2, lfcW1A2) and
+// the one XNOR stage with a 2-bit output (lfcW1A2 layer 0).  Same structure and
+// the same integer-pipe discipline as the XNOR kernels above; per 32 synapses
+//   AR_TB  v_bitop3 (za & (sa ^ w)) + v_bcnt                       2 slots, like XNOR
+//   AR_TT  v_and (za & zw) + v_bcnt + v_bitop3 (.. & (sa ^ sw)) + v_bcnt   4 slots
+// and the activation is decided on the sign of
+//   g0 = q + c0,  g1 = g0 + (t1 - t0),   fire_i  <=>  g_i < 0
+//   AR_XNOR q = m            c0 = -t0        (m < t)
+//   AR_TB   q = 2m - nz(a)   c0 = t0         (t < nz - 2m)
+//   AR_TT   q = 2m - z       c0 = t0         (t < z - 2m)
+// Max-pool = min of q over the quad (thresholding is monotone).
+// ---------------------------------------------------------------------------
+// truth table index = src0<<2 | src1<<1 | src2; f = src2 & (src0 ^ src1) -> rows 3 and 5
+#define BNN_BITOP_AND_XOR "0x28"
+
+// one 32-bit half of a weight word against one 32-bit half of an activation word.
+// wq: this word's weight dwords {lo, hi} (XNOR, TB) or {sign lo, sign hi, nz lo, nz hi} (TT)
+template <int ARITH>
+__device__ __forceinline__ void mac32(int &m, int &z, uint32_t as, uint32_t az, kptr32 wq, int half) {
+  uint32_t t0, t1;
+  if constexpr (ARITH == AR_XNOR) {
+    asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "=&v"(t0), "+v"(m) : "s"(wq[half]), "v"(as));
+  } else if constexpr (ARITH == AR_TB) {
+    asm("v_bitop3_b32 %0, %2, %3, %4 bitop3:" BNN_BITOP_AND_XOR "\n\tv_bcnt_u32_b32 %1, %0, %1"
+        : "=&v"(t0), "+v"(m)
+        : "s"(wq[half]), "v"(as), "v"(az));
+  } else {
+    asm("v_and_b32 %0, %4, %5\n\tv_bcnt_u32_b32 %2, %0, %2\n\t"
+        "v_bitop3_b32 %1, %6, %7, %0 bitop3:" BNN_BITOP_AND_XOR "\n\tv_bcnt_u32_b32 %3, %1, %3"
+        : "=&v"(t0), "=&v"(t1), "+v"(z), "+v"(m)
+        : "s"(wq[2 + half]), "v"(az), "s"(wq[half]), "v"(as));
+  }
+}
+
+template <int ARITH>
+__device__ __forceinline__ int q_of(int m, int z, int neg_nzt) {
+  if constexpr (ARITH == AR_XNOR) return m;
+  else if constexpr (ARITH == AR_TB) return (m << 1) + neg_nzt;
+  else return (m << 1) - z;
+}
+
+// shift the decision(s) on g0 into the result word(s).  1-bit out: fire0.  2-bit out: the
+// planes are collected inverted (sign: f0|f1 ... see finish_bits) and fixed once per 32 neurons.
+template <bool OUT2>
+__device__ __forceinline__ void decide(uint32_t &b0, uint32_t &b1, int g0, int dt) {
+  if constexpr (!OUT2) {
+    b0 = shift_in_sign(b0, g0);
+  } else {
+    const int g1 = g0 + dt;
+    b0 = shift_in_sign(b0, g0 | g1);  // f0 | f1      -> sign plane    = ~
+    b1 = shift_in_sign(b1, g0 ^ g1);  // f0 != f1     -> non-zero plane = ~
+  }
+}
+template <bool OUT2>
+__device__ __forceinline__ void finish_bits(uint32_t &b0, uint32_t &b1) {
+  if constexpr (OUT2) { b0 = ~b0; b1 = ~b1; }
+}
+
+// 3x3 valid conv, one lane = a 2x2 quad of output pixels (4x4 window in VGPRs), optional pool.
+// Replaces ConvolutionInputGenerator + Matrix_Vector_Activate_Batch + ThresholdsActivation
+// (+ StreamingMaxPool_Precision_Batch) for CNV layers 1..3 of the A2 networks.
+template <int ARITH, int CW, int ID, bool POOL, bool OUT2>
+__global__ __launch_bounds__(kBlock) void k_quad(const uint64_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                  const uint32_t *__restrict__ rows, int n_items) {
+  constexpr int OD = ID - 2, QD = OD / 2, NQ = QD * QD, PL = planes_in<ARITH>(), WPL = wplanes<ARITH>();
+  constexpr int KW = 9 * CW, ROW_DW = 2 + 2 * KW * WPL, ZW = (PL == 2) ? CW : 1;
+  const int item = blockIdx.x * kBlock + threadIdx.x;
+  if (item >= n_items) return;
+  const int img = item / NQ, q = item - img * NQ;
+  const int qy = q / QD, qx = q - qy * QD;
+  const uint64_t *__restrict__ base = in + ((size_t)img * ID * ID + (size_t)(2 * qy) * ID + 2 * qx) * CW * PL;
+  uint32_t ws[4][4][CW][2], wz[4][4][ZW][2];
+#pragma unroll
+  for (int y = 0; y < 4; y++)
+#pragma unroll
+    for (int x = 0; x < 4; x++)
+#pragma unroll
+      for (int k = 0; k < CW; k++) {
+        const uint64_t v = base[((y * ID + x) * CW + k) * PL];
+        ws[y][x][k][0] = (uint32_t)v; ws[y][x][k][1] = (uint32_t)(v >> 32);
+        if constexpr (PL == 2) {
+          const uint64_t u = base[((y * ID + x) * CW + k) * PL + 1];
+          wz[y][x][k][0] = (uint32_t)u; wz[y][x][k][1] = (uint32_t)(u >> 32);
+        }
+      }
+  // AR_TB: minus the number of non-zero activations in each of the 4 windows (weight independent)
+  int nn[2][2] = {{0, 0}, {0, 0}};
+  if constexpr (ARITH == AR_TB) {
+#pragma unroll
+    for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+      for (int dx = 0; dx < 2; dx++)
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+          for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+            for (int k = 0; k < CW; k++)
+              nn[dy][dx] -= __builtin_popcount(wz[dy + ky][dx + kx][k][0]) + __builtin_popcount(wz[dy + ky][dx + kx][k][1]);
+  }
+  kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)blockIdx.y * 32 * ROW_DW);
+  uint32_t b0[4] = {0, 0, 0, 0}, b1[4] = {0, 0, 0, 0};
+  for (int c = 31; c >= 0; c--) {
+    kptr32 r = w + c * ROW_DW;
+    const int t0 = (int)r[0], t1 = (int)r[1];
+    const int c0 = (ARITH == AR_XNOR) ? -t0 : t0, dt = (ARITH == AR_XNOR) ? (t0 - t1) : (t1 - t0);
+    int m[2][2] = {{0, 0}, {0, 0}}, z[2][2] = {{0, 0}, {0, 0}};
+#pragma unroll
+    for (int j = 0; j < KW; j++) {
+      const int ky = j / (3 * CW), kx = (j / CW) % 3, k = j % CW;
+      kptr32 wq = r + 2 + 2 * WPL * j;
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+          for (int dx = 0; dx < 2; dx++)
+            mac32<ARITH>(m[dy][dx], z[dy][dx], ws[dy + ky][dx + kx][k][h], wz[dy + ky][dx + kx][PL == 2 ? k : 0][h], wq, h);
+    }
+    if constexpr (POOL) {
+      const int q0 = q_of<ARITH>(m[0][0], z[0][0], nn[0][0]), q1 = q_of<ARITH>(m[0][1], z[0][1], nn[0][1]);
+      const int q2 = q_of<ARITH>(m[1][0], z[1][0], nn[1][0]), q3 = q_of<ARITH>(m[1][1], z[1][1], nn[1][1]);
+      decide<OUT2>(b0[0], b1[0], min(min(q0, q1), min(q2, q3)) + c0, dt);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+        decide<OUT2>(b0[i], b1[i], q_of<ARITH>(m[i >> 1][i & 1], z[i >> 1][i & 1], nn[i >> 1][i & 1]) + c0, dt);
+    }
+  }
+  const int groups = gridDim.y;
+  if constexpr (POOL) {
+    finish_bits<OUT2>(b0[0], b1[0]);
+    store_bits<OUT2>(out, (size_t)item, groups, blockIdx.y, b0[0], b1[0]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const size_t pix = (size_t)img * OD * OD + (size_t)(2 * qy + (i >> 1)) * OD + 2 * qx + (i & 1);
+      finish_bits<OUT2>(b0[i], b1[i]);
+      store_bits<OUT2>(out, pix, groups, blockIdx.y, b0[i], b1[i]);
+    }
+  }
+}
+
+// Generic "KW words in, thresholded bits out": one lane = one vector (FC layers, CNV layer 5,
+// and with SINGLE the 3x3 window gather of CNV layer 4).  Two neurons per iteration.
+template <int ARITH, int KW, bool OUT2, bool SINGLE, int CW, int ID>
+__global__ __launch_bounds__(kBlock) void k_vec(const uint64_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                 const uint32_t *__restrict__ rows, int n_items) {
+  constexpr int PL = planes_in<ARITH>(), WPL = wplanes<ARITH>();
+  constexpr int ROW_DW = 2 + 2 * KW * WPL, ZW = (PL == 2) ? KW : 1;
+  const int item = blockIdx.x * kBlock + threadIdx.x;
+  if (item >= n_items) return;
+  uint32_t as[KW][2], az[ZW][2];
+  auto load_word = [&](int dst, const uint64_t *__restrict__ src) {
+    const uint64_t v = src[0];
+    as[dst][0] = (uint32_t)v; as[dst][1] = (uint32_t)(v >> 32);
+    if constexpr (PL == 2) {
+      const uint64_t u = src[1];
+      az[dst][0] = (uint32_t)u; az[dst][1] = (uint32_t)(u >> 32);
+    }
+  };
+  if constexpr (SINGLE) {
+    constexpr int OD = ID - 2;
+    static_assert(KW == 9 * CW, "window size");
+    const int img = item / (OD * OD), p = item - img * (OD * OD);
+    const int oy = p / OD, ox = p - oy * OD;
+    const uint64_t *__restrict__ base = in + ((size_t)img * ID * ID + (size_t)oy * ID + ox) * CW * PL;
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+        for (int k = 0; k < CW; k++) load_word((ky * 3 + kx) * CW + k, base + ((ky * ID + kx) * CW + k) * PL);
+  } else {
+    const uint64_t *__restrict__ base = in + (size_t)item * KW * PL;
+#pragma unroll
+    for (int k = 0; k < KW; k++) load_word(k, base + k * PL);
+  }
+  int nn = 0;
+  if constexpr (ARITH == AR_TB) {
+#pragma unroll
+    for (int k = 0; k < KW; k++) nn -= __builtin_popcount(az[k][0]) + __builtin_popcount(az[k][1]);
+  }
+  kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)blockIdx.y * 32 * ROW_DW);
+  uint32_t b0 = 0, b1 = 0;
+  for (int c = 31; c >= 0; c -= 2) {
+    kptr32 rA = w + c * ROW_DW, rB = rA - ROW_DW;
+    int mA = 0, zA = 0, mB = 0, zB = 0;
+#pragma unroll
+    for (int k = 0; k < KW; k++)
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        mac32<ARITH>(mA, zA, as[k][h], az[PL == 2 ? k : 0][h], rA + 2 + 2 * WPL * k, h);
+        mac32<ARITH>(mB, zB, as[k][h], az[PL == 2 ? k : 0][h], rB + 2 + 2 * WPL * k, h);
+      }
+    const int tA0 = (int)rA[0], tA1 = (int)rA[1], tB0 = (int)rB[0], tB1 = (int)rB[1];
+    if constexpr (ARITH == AR_XNOR) {
+      decide<OUT2>(b0, b1, mA - tA0, tA0 - tA1);
+      decide<OUT2>(b0, b1, mB - tB0, tB0 - tB1);
+    } else {
+      decide<OUT2>(b0, b1, q_of<ARITH>(mA, zA, nn) + tA0, tA1 - tA0);
+      decide<OUT2>(b0, b1, q_of<ARITH>(mB, zB, nn) + tB0, tB1 - tB0);
+    }
+  }
+  finish_bits<OUT2>(b0, b1);
+  store_bits<OUT2>(out, (size_t)item, gridDim.y, blockIdx.y, b0, b1);
 }
 
 // ---------------------------------------------------------------------------
