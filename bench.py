@@ -29,7 +29,21 @@ import torch  # before the product library: one HIP runtime per process (INTEGRA
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "bnn-pynq_amd"))
 import gpu_lib as gl  # noqa: E402  (ctypes binding of the product C ABI)
+from bnn import multigpu as mg  # noqa: E402  (packed-blob broadcast, shard helpers)
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
 
 # algorithmic bytes per image of the fused path (SURVEY.md 8(d)): 3072 in + 4 out
 ALG_BYTES = {"cnv": 3072 + 4, "lfc": 784 + 4}
@@ -86,17 +100,9 @@ def main():
         if err:
             sys.exit(err)
     else:
-        if rank == 0:
-            blob = torch.from_numpy(gl.pack_params(a.network, pdir))
-            size = torch.tensor([blob.numel()], dtype=torch.int64, device=dev)
-        else:
-            size = torch.zeros(1, dtype=torch.int64, device=dev)
-        dist.broadcast(size, 0)
-        d_blob = blob.to(dev) if rank == 0 else torch.empty(int(size.item()), dtype=torch.uint8, device=dev)
-        dist.broadcast(d_blob, 0)  # the one collective of the whole job (xGMI, ~210 KB)
-        host = d_blob.cpu().numpy()
-        if L.bnn_mi355x_import_params(host.ctypes.data, host.size) != 0:
-            sys.exit(L.bnn_mi355x_last_error().decode())
+        # rank 0 reads + repacks the files; the ~210 KB blob goes to the other GPUs over RCCL/xGMI:
+        # the one collective of the whole job
+        mg.distribute_params(L, pdir, device=dev)
 
     # ---- synthetic batch, resident in HBM before the timed region starts
     g = torch.Generator(device=dev)
@@ -185,7 +191,7 @@ def main():
         import oracle_lib as ol
         o = ol.Oracle(a.network, ol.param_dir(dataset, a.network))
         host = imgs[: min(a.batch, 65536)].cpu().numpy()
-        cores = os.cpu_count() or 1
+        cores = host_cores()
         probe = min(256, host.shape[0])
         run = (lambda x: o.scores_fast(x, cores)) if is_cnv else (lambda x: o.words_fast(x, cores))
         t1 = time.perf_counter()
