@@ -48,10 +48,21 @@ def host_cores():
 # algorithmic bytes per image of the fused path: 3072 in + 4 out
 ALG_BYTES = {"cnv": 3072 + 4, "lfc": 784 + 4}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-VALU_PEAK_TOPS = 78.64         # 256 CU x 4 SIMD x 32 lanes x 2.4 GHz, one 32-bit lane-op each
-# VALU lane-ops per image: 4 per 64-bit XNOR-popcount word (2 v_xor + 2 v_bcnt), 905 216 words;
-# layer 0: 900 px x 64 ch x 9 v_dot4
-VALU_OPS = {"cnvW1A1": 905216 * 4 + 900 * 64 * 9, "lfcW1A1": 47104 * 4}
+# Integer-pipe issue floor (measured in profiles/r01_microbench*.txt): a wave64
+# v_xor/v_bitop3 + v_bcnt pair (32 synapses per lane) sustains 6.6 SIMD-cycles; v_dot4c and every other
+# VOP3 / SGPR-operand integer op 4.2; 1024 SIMDs; 2.38 GHz held under this load.
+PAIR_CYC, SLOT_CYC, N_SIMD, CLK_HZ = 6.6, 4.2, 1024, 2.38e9
+WORD_MACS = {"cnv": 905216, "lfc": 47104}          # 64-bit word-MACs per image, layers 1..
+PAIRS_PER_WORD = {"W1A1": 2, "W1A2": 2, "W2A2": 4}  # (logic op + v_bcnt) pairs per 64-bit word-MAC
+
+
+def issue_floor_cycles(network):
+    """SIMD-cycles per image if the integer pipe issued nothing but the unavoidable instructions"""
+    kind, prec = network[:3], network[3:]
+    cyc = WORD_MACS[kind] * PAIRS_PER_WORD[prec] * PAIR_CYC
+    if kind == "cnv":
+        cyc += 900 * 64 * 8 * SLOT_CYC              # layer 0: 7 v_dot4c + 1 v_alignbit per pixel and neuron
+    return cyc / 64.0                                # 64 lanes per wave instruction
 
 
 def parse():
@@ -180,11 +191,13 @@ def main():
                       % (a.network, a.batch, "32x32x3 uint8" if is_cnv else "28x28 uint8", dataset, a.network),
                       "images_per_gpu_per_step": a.batch, "parallelism": "dp%d (batch shards, no data-path collective)" % world},
            "roofline": roofline}
-    if a.network in VALU_OPS:
-        tops = VALU_OPS[a.network] * a.batch / (dev_ms * 1e-3) / 1e12
-        out["valu"] = {"lane_ops_per_image": VALU_OPS[a.network], "achieved": round(tops, 3), "peak": VALU_PEAK_TOPS,
-                       "unit": "T lane-op/s", "frac": round(tops / VALU_PEAK_TOPS, 4),
-                       "note": "the path is integer-VALU bound (v_xor + v_bcnt), not HBM bound: this is the meaningful ceiling"}
+    floor_cyc = issue_floor_cycles(a.network)
+    ceiling = N_SIMD * CLK_HZ / floor_cyc            # images/s per GPU at the issue floor
+    per_gpu = a.batch / (dev_ms * 1e-3)
+    out["valu"] = {"bound": "integer-pipe issue (v_xor/v_bitop3 + v_bcnt pairs, v_dot4c)", "achieved": round(per_gpu, 1),
+                   "peak": round(ceiling, 1), "unit": "images/s per GPU", "frac": round(per_gpu / ceiling, 4),
+                   "simd_cycles_per_image_floor": round(floor_cyc, 1), "clock_ghz": CLK_HZ / 1e9,
+                   "note": "the path is bound by integer VALU issue, not HBM: this is the meaningful ceiling (DESIGN.md 5)"}
 
     # ---- CPU baseline: the CPU restatement on this host's cores, bounded sample, same images
     if world == 1 and not a.no_cpu_baseline:

@@ -42,6 +42,24 @@ typedef const uint64_t __attribute__((address_space(4))) *kptr64;
 
 constexpr int kBlock = 256;
 
+// Block -> (work-item block, neuron group), XCD-aware.  The `groups` blocks that evaluate
+// different 32-neuron groups for the SAME 256 work items read the same input windows and write
+// the interleaved dwords of the same output lines.  Workgroups are dealt round-robin over the 8
+// XCDs (each with its own L2), so those blocks are given ids that are congruent mod 8 and
+// adjacent in dispatch order: the re-reads then hit that XCD's L2 and the partial-line writes
+// merge there instead of going to HBM once per group (measured: profiles/r01_pmc_*).
+// Placement only affects speed/traffic, never results.
+struct BlockMap { int cg, item; bool valid; };
+__device__ __forceinline__ BlockMap map_block(int groups, int n_items) {
+  const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+  const int sg = slot / groups;
+  BlockMap m;
+  m.cg = slot - sg * groups;
+  m.item = (sg * 8 + xcd) * kBlock + threadIdx.x;
+  m.valid = m.item < n_items;
+  return m;
+}
+
 __device__ __forceinline__ int pc64(uint64_t x) { return __builtin_popcountll(x); }
 
 // ---------------------------------------------------------------------------
@@ -146,9 +164,10 @@ __device__ __forceinline__ uint32_t shift_in_sign(uint32_t bits, int v) {
 
 template <bool OUT2>
 __global__ __launch_bounds__(kBlock) void k_conv0(const uint8_t *__restrict__ imgs, uint32_t *__restrict__ out,
-                                                   const uint32_t *__restrict__ rows, int n_items) {
-  const int item = blockIdx.x * kBlock + threadIdx.x;
-  if (item >= n_items) return;
+                                                   const uint32_t *__restrict__ rows, int n_items, int groups, int gpb) {
+  const BlockMap bm = map_block(groups / gpb, n_items);
+  if (!bm.valid) return;
+  const int item = bm.item;
   const int img = item / 900, p = item - img * 900;
   const int oy = p / 30, ox = p - oy * 30;
   const uint32_t *__restrict__ im32 = reinterpret_cast<const uint32_t *>(imgs + (size_t)img * 3072);
@@ -175,38 +194,42 @@ __global__ __launch_bounds__(kBlock) void k_conv0(const uint8_t *__restrict__ im
   a[6] = g[8];  // taps 24..26 + one don't-care byte (its weight byte is 0)
 #pragma unroll
   for (int j = 0; j < 7; j++) a[j] = quantise4(a[j]);
-  kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)blockIdx.y * 32 * 12);
-  uint32_t b0 = 0, b1 = 0;
-  // Two neurons per iteration (two independent v_dot4c chains, strictly alternating).  Each
-  // accumulator starts at ~t = -t-1, so that afterwards  acc < 0  <=>  dot <= t  <=>  !fire:
-  // the threshold test costs no instruction, its result is the accumulator's sign bit.
-  for (int c = 31; c >= 0; c -= 2) {
-    kptr32 rA = w + c * 12, rB = rA - 12;
-    int accA = ~(int)rA[0], accB = ~(int)rB[0];
-#pragma unroll
-    for (int k = 0; k < 7; k++) {
-      // (builtin, not inline asm: a VALU read of a v_dot4c result needs wait states that only
-      // the compiler's hazard recogniser inserts; the empty asm just pins the issue order)
-      accA = __builtin_amdgcn_sdot4((int)a[k], (int)rA[2 + k], accA, false);
-      asm("" : "+v"(accA));
-      accB = __builtin_amdgcn_sdot4((int)a[k], (int)rB[2 + k], accB, false);
-      asm("" : "+v"(accB));
+  // neuron groups handled by this block: gpb = all of them for large batches (one lane then
+  // writes whole output words), 1 for small ones (more blocks in flight)
+  for (int cg = bm.cg * gpb, cg_end = cg + gpb; cg < cg_end; cg++) {
+    kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)cg * 32 * 12);
+    uint32_t b0 = 0, b1 = 0;
+    // Two neurons per iteration (two independent v_dot4c chains, strictly alternating).  Each
+    // accumulator starts at ~t = -t-1, so that afterwards  acc < 0  <=>  dot <= t  <=>  !fire:
+    // the threshold test costs no instruction, its result is the accumulator's sign bit.
+    for (int c = 31; c >= 0; c -= 2) {
+      kptr32 rA = w + c * 12, rB = rA - 12;
+      int accA = ~(int)rA[0], accB = ~(int)rB[0];
+  #pragma unroll
+      for (int k = 0; k < 7; k++) {
+        // (builtin, not inline asm: a VALU read of a v_dot4c result needs wait states that only
+        // the compiler's hazard recogniser inserts; the empty asm just pins the issue order)
+        accA = __builtin_amdgcn_sdot4((int)a[k], (int)rA[2 + k], accA, false);
+        asm("" : "+v"(accA));
+        accB = __builtin_amdgcn_sdot4((int)a[k], (int)rB[2 + k], accB, false);
+        asm("" : "+v"(accB));
+      }
+      if constexpr (!OUT2) {
+        b0 = shift_in_sign(b0, accA);
+        b0 = shift_in_sign(b0, accB);
+      } else {
+        // second threshold: dot - t1 - 1 = acc + (t0 - t1)
+        const int dA = accA + ((int)rA[0] - (int)rA[1]), dB = accB + ((int)rB[0] - (int)rB[1]);
+        b0 = shift_in_sign(b0, accA & dA);  // sign plane: !f0 & !f1
+        b1 = shift_in_sign(b1, accA ^ dA);  // (f0 != f1): inverted below
+        b0 = shift_in_sign(b0, accB & dB);
+        b1 = shift_in_sign(b1, accB ^ dB);
+      }
     }
-    if constexpr (!OUT2) {
-      b0 = shift_in_sign(b0, accA);
-      b0 = shift_in_sign(b0, accB);
-    } else {
-      // second threshold: dot - t1 - 1 = acc + (t0 - t1)
-      const int dA = accA + ((int)rA[0] - (int)rA[1]), dB = accB + ((int)rB[0] - (int)rB[1]);
-      b0 = shift_in_sign(b0, accA & dA);  // sign plane: !f0 & !f1
-      b1 = shift_in_sign(b1, accA ^ dA);  // (f0 != f1): inverted below
-      b0 = shift_in_sign(b0, accB & dB);
-      b1 = shift_in_sign(b1, accB ^ dB);
-    }
+    if constexpr (!OUT2) b0 = ~b0;  // collected !fire
+    else b1 = ~b1;
+    store_bits<OUT2>(out, (size_t)item, 2, cg, b0, b1);
   }
-  if constexpr (!OUT2) b0 = ~b0;  // collected !fire
-  else b1 = ~b1;
-  store_bits<OUT2>(out, (size_t)item, 2, blockIdx.y, b0, b1);
 }
 
 // ---------------------------------------------------------------------------
@@ -258,10 +281,11 @@ __device__ __forceinline__ int xpop0(uint32_t w, uint32_t a) {
 }
 template <int CW, int ID, bool POOL>
 __global__ __launch_bounds__(kBlock) void k_quad_x(const uint64_t *__restrict__ in, uint32_t *__restrict__ out,
-                                                    const uint32_t *__restrict__ rows, int n_items) {
+                                                    const uint32_t *__restrict__ rows, int n_items, int groups, int gpb) {
   constexpr int OD = ID - 2, QD = OD / 2, NQ = QD * QD, KW = 9 * CW, ROW_DW = 2 + 2 * KW;
-  const int item = blockIdx.x * kBlock + threadIdx.x;
-  if (item >= n_items) return;
+  const BlockMap bm = map_block(groups / gpb, n_items);
+  if (!bm.valid) return;
+  const int item = bm.item;
   const int img = item / NQ, q = item - img * NQ;
   const int qy = q / QD, qx = q - qy * QD;
   const uint64_t *__restrict__ base = in + ((size_t)img * ID * ID + (size_t)(2 * qy) * ID + 2 * qx) * CW;
@@ -276,35 +300,36 @@ __global__ __launch_bounds__(kBlock) void k_quad_x(const uint64_t *__restrict__ 
         wl[y][x][k] = (uint32_t)v;
         wh[y][x][k] = (uint32_t)(v >> 32);
       }
-  kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)blockIdx.y * 32 * ROW_DW);
-  uint32_t b[4] = {0, 0, 0, 0};
-  for (int c = 31; c >= 0; c--) {
-    kptr32 r = w + c * ROW_DW;
-    const int t = (int)r[0];
-    int m[2][2] = {{0, 0}, {0, 0}};
-#pragma unroll
-    for (int j = 0; j < KW; j++) {
-      const int ky = j / (3 * CW), kx = (j / CW) % 3, k = j % CW;
-      const uint32_t w0 = r[2 + 2 * j], w1 = r[3 + 2 * j];
-      xpop4(m[0][0], m[0][1], m[1][0], m[1][1], w0, wl[ky][kx][k], wl[ky][kx + 1][k], wl[ky + 1][kx][k], wl[ky + 1][kx + 1][k]);
-      xpop4(m[0][0], m[0][1], m[1][0], m[1][1], w1, wh[ky][kx][k], wh[ky][kx + 1][k], wh[ky + 1][kx][k], wh[ky + 1][kx + 1][k]);
+  for (int cg = bm.cg * gpb, cg_end = cg + gpb; cg < cg_end; cg++) {  // see k_conv0
+    kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)cg * 32 * ROW_DW);
+    uint32_t b[4] = {0, 0, 0, 0};
+    for (int c = 31; c >= 0; c--) {
+      kptr32 r = w + c * ROW_DW;
+      const int t = (int)r[0];
+      int m[2][2] = {{0, 0}, {0, 0}};
+  #pragma unroll
+      for (int j = 0; j < KW; j++) {
+        const int ky = j / (3 * CW), kx = (j / CW) % 3, k = j % CW;
+        const uint32_t w0 = r[2 + 2 * j], w1 = r[3 + 2 * j];
+        xpop4(m[0][0], m[0][1], m[1][0], m[1][1], w0, wl[ky][kx][k], wl[ky][kx + 1][k], wl[ky + 1][kx][k], wl[ky + 1][kx + 1][k]);
+        xpop4(m[0][0], m[0][1], m[1][0], m[1][1], w1, wh[ky][kx][k], wh[ky][kx + 1][k], wh[ky + 1][kx][k], wh[ky + 1][kx + 1][k]);
+      }
+      if constexpr (POOL) {  // OR of the four fire bits == (min m) < t
+        const int mn = min(min(m[0][0], m[0][1]), min(m[1][0], m[1][1]));
+        b[0] = shift_in_sign(b[0], mn - t);
+      } else {
+  #pragma unroll
+        for (int i = 0; i < 4; i++) b[i] = shift_in_sign(b[i], m[i >> 1][i & 1] - t);
+      }
     }
-    if constexpr (POOL) {  // OR of the four fire bits == (min m) < t
-      const int mn = min(min(m[0][0], m[0][1]), min(m[1][0], m[1][1]));
-      b[0] = shift_in_sign(b[0], mn - t);
+    if constexpr (POOL) {
+      out[(size_t)item * groups + cg] = b[0];
     } else {
-#pragma unroll
-      for (int i = 0; i < 4; i++) b[i] = shift_in_sign(b[i], m[i >> 1][i & 1] - t);
-    }
-  }
-  const int groups = gridDim.y;
-  if constexpr (POOL) {
-    out[(size_t)item * groups + blockIdx.y] = b[0];
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const size_t pix = (size_t)img * OD * OD + (size_t)(2 * qy + (i >> 1)) * OD + 2 * qx + (i & 1);
-      out[pix * groups + blockIdx.y] = b[i];
+  #pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const size_t pix = (size_t)img * OD * OD + (size_t)(2 * qy + (i >> 1)) * OD + 2 * qx + (i & 1);
+        out[pix * groups + cg] = b[i];
+      }
     }
   }
 }
@@ -313,10 +338,11 @@ __global__ __launch_bounds__(kBlock) void k_quad_x(const uint64_t *__restrict__ 
 // Two neurons per iteration: two independent v_bcnt chains per lane.
 template <int KW, bool SINGLE, int CW, int ID>
 __global__ __launch_bounds__(kBlock) void k_vec_x(const uint64_t *__restrict__ in, uint32_t *__restrict__ out,
-                                                   const uint32_t *__restrict__ rows, int n_items) {
+                                                   const uint32_t *__restrict__ rows, int n_items, int groups, int gpb) {
   constexpr int ROW_DW = 2 + 2 * KW;
-  const int item = blockIdx.x * kBlock + threadIdx.x;
-  if (item >= n_items) return;
+  const BlockMap bm = map_block(groups / gpb, n_items);
+  if (!bm.valid) return;
+  const int item = bm.item;
   uint32_t al[KW], ah[KW];
   if constexpr (SINGLE) {
     constexpr int OD = ID - 2;
@@ -343,24 +369,26 @@ __global__ __launch_bounds__(kBlock) void k_vec_x(const uint64_t *__restrict__ i
       ah[k] = (uint32_t)(v >> 32);
     }
   }
-  kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)blockIdx.y * 32 * ROW_DW);
-  uint32_t b = 0;
-  for (int c = 31; c >= 0; c -= 2) {
-    kptr32 r1 = w + c * ROW_DW, r0 = r1 - ROW_DW;
-    int m1 = xpop0(r1[2], al[0]), m0 = xpop0(r0[2], al[0]);
-    xpop(m1, r1[3], ah[0]);
-    xpop(m0, r0[3], ah[0]);
-#pragma unroll
-    for (int k = 1; k < KW; k++) {
-      xpop(m1, r1[2 + 2 * k], al[k]);
-      xpop(m0, r0[2 + 2 * k], al[k]);
-      xpop(m1, r1[3 + 2 * k], ah[k]);
-      xpop(m0, r0[3 + 2 * k], ah[k]);
+  for (int cg = bm.cg * gpb, cg_end = cg + gpb; cg < cg_end; cg++) {  // see k_conv0
+    kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)cg * 32 * ROW_DW);
+    uint32_t b = 0;
+    for (int c = 31; c >= 0; c -= 2) {
+      kptr32 r1 = w + c * ROW_DW, r0 = r1 - ROW_DW;
+      int m1 = xpop0(r1[2], al[0]), m0 = xpop0(r0[2], al[0]);
+      xpop(m1, r1[3], ah[0]);
+      xpop(m0, r0[3], ah[0]);
+  #pragma unroll
+      for (int k = 1; k < KW; k++) {
+        xpop(m1, r1[2 + 2 * k], al[k]);
+        xpop(m0, r0[2 + 2 * k], al[k]);
+        xpop(m1, r1[3 + 2 * k], ah[k]);
+        xpop(m0, r0[3 + 2 * k], ah[k]);
+      }
+      b = shift_in_sign(b, m1 - (int)r1[0]);
+      b = shift_in_sign(b, m0 - (int)r0[0]);
     }
-    b = shift_in_sign(b, m1 - (int)r1[0]);
-    b = shift_in_sign(b, m0 - (int)r0[0]);
+    out[(size_t)item * groups + cg] = b;
   }
-  out[(size_t)item * gridDim.y + blockIdx.y] = b;
 }
 
 
@@ -428,11 +456,12 @@ __device__ __forceinline__ void finish_bits(uint32_t &b0, uint32_t &b1) {
 // (+ StreamingMaxPool_Precision_Batch) for CNV layers 1..3 of the A2 networks.
 template <int ARITH, int CW, int ID, bool POOL, bool OUT2>
 __global__ __launch_bounds__(kBlock) void k_quad(const uint64_t *__restrict__ in, uint32_t *__restrict__ out,
-                                                  const uint32_t *__restrict__ rows, int n_items) {
+                                                  const uint32_t *__restrict__ rows, int n_items, int groups, int gpb) {
   constexpr int OD = ID - 2, QD = OD / 2, NQ = QD * QD, PL = planes_in<ARITH>(), WPL = wplanes<ARITH>();
   constexpr int KW = 9 * CW, ROW_DW = 2 + 2 * KW * WPL, ZW = (PL == 2) ? CW : 1;
-  const int item = blockIdx.x * kBlock + threadIdx.x;
-  if (item >= n_items) return;
+  const BlockMap bm = map_block(groups / gpb, n_items);
+  if (!bm.valid) return;
+  const int item = bm.item;
   const int img = item / NQ, q = item - img * NQ;
   const int qy = q / QD, qx = q - qy * QD;
   const uint64_t *__restrict__ base = in + ((size_t)img * ID * ID + (size_t)(2 * qy) * ID + 2 * qx) * CW * PL;
@@ -465,45 +494,46 @@ __global__ __launch_bounds__(kBlock) void k_quad(const uint64_t *__restrict__ in
             for (int k = 0; k < CW; k++)
               nn[dy][dx] -= __builtin_popcount(wz[dy + ky][dx + kx][k][0]) + __builtin_popcount(wz[dy + ky][dx + kx][k][1]);
   }
-  kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)blockIdx.y * 32 * ROW_DW);
-  uint32_t b0[4] = {0, 0, 0, 0}, b1[4] = {0, 0, 0, 0};
-  for (int c = 31; c >= 0; c--) {
-    kptr32 r = w + c * ROW_DW;
-    const int t0 = (int)r[0], t1 = (int)r[1];
-    const int c0 = (ARITH == AR_XNOR) ? -t0 : t0, dt = (ARITH == AR_XNOR) ? (t0 - t1) : (t1 - t0);
-    int m[2][2] = {{0, 0}, {0, 0}}, z[2][2] = {{0, 0}, {0, 0}};
-#pragma unroll
-    for (int j = 0; j < KW; j++) {
-      const int ky = j / (3 * CW), kx = (j / CW) % 3, k = j % CW;
-      kptr32 wq = r + 2 + 2 * WPL * j;
-#pragma unroll
-      for (int h = 0; h < 2; h++)
-#pragma unroll
-        for (int dy = 0; dy < 2; dy++)
-#pragma unroll
-          for (int dx = 0; dx < 2; dx++)
-            mac32<ARITH>(m[dy][dx], z[dy][dx], ws[dy + ky][dx + kx][k][h], wz[dy + ky][dx + kx][PL == 2 ? k : 0][h], wq, h);
+  for (int cg = bm.cg * gpb, cg_end = cg + gpb; cg < cg_end; cg++) {  // see k_conv0
+    kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)cg * 32 * ROW_DW);
+    uint32_t b0[4] = {0, 0, 0, 0}, b1[4] = {0, 0, 0, 0};
+    for (int c = 31; c >= 0; c--) {
+      kptr32 r = w + c * ROW_DW;
+      const int t0 = (int)r[0], t1 = (int)r[1];
+      const int c0 = (ARITH == AR_XNOR) ? -t0 : t0, dt = (ARITH == AR_XNOR) ? (t0 - t1) : (t1 - t0);
+      int m[2][2] = {{0, 0}, {0, 0}}, z[2][2] = {{0, 0}, {0, 0}};
+  #pragma unroll
+      for (int j = 0; j < KW; j++) {
+        const int ky = j / (3 * CW), kx = (j / CW) % 3, k = j % CW;
+        kptr32 wq = r + 2 + 2 * WPL * j;
+  #pragma unroll
+        for (int h = 0; h < 2; h++)
+  #pragma unroll
+          for (int dy = 0; dy < 2; dy++)
+  #pragma unroll
+            for (int dx = 0; dx < 2; dx++)
+              mac32<ARITH>(m[dy][dx], z[dy][dx], ws[dy + ky][dx + kx][k][h], wz[dy + ky][dx + kx][PL == 2 ? k : 0][h], wq, h);
+      }
+      if constexpr (POOL) {
+        const int q0 = q_of<ARITH>(m[0][0], z[0][0], nn[0][0]), q1 = q_of<ARITH>(m[0][1], z[0][1], nn[0][1]);
+        const int q2 = q_of<ARITH>(m[1][0], z[1][0], nn[1][0]), q3 = q_of<ARITH>(m[1][1], z[1][1], nn[1][1]);
+        decide<OUT2>(b0[0], b1[0], min(min(q0, q1), min(q2, q3)) + c0, dt);
+      } else {
+  #pragma unroll
+        for (int i = 0; i < 4; i++)
+          decide<OUT2>(b0[i], b1[i], q_of<ARITH>(m[i >> 1][i & 1], z[i >> 1][i & 1], nn[i >> 1][i & 1]) + c0, dt);
+      }
     }
     if constexpr (POOL) {
-      const int q0 = q_of<ARITH>(m[0][0], z[0][0], nn[0][0]), q1 = q_of<ARITH>(m[0][1], z[0][1], nn[0][1]);
-      const int q2 = q_of<ARITH>(m[1][0], z[1][0], nn[1][0]), q3 = q_of<ARITH>(m[1][1], z[1][1], nn[1][1]);
-      decide<OUT2>(b0[0], b1[0], min(min(q0, q1), min(q2, q3)) + c0, dt);
+      finish_bits<OUT2>(b0[0], b1[0]);
+      store_bits<OUT2>(out, (size_t)item, groups, cg, b0[0], b1[0]);
     } else {
-#pragma unroll
-      for (int i = 0; i < 4; i++)
-        decide<OUT2>(b0[i], b1[i], q_of<ARITH>(m[i >> 1][i & 1], z[i >> 1][i & 1], nn[i >> 1][i & 1]) + c0, dt);
-    }
-  }
-  const int groups = gridDim.y;
-  if constexpr (POOL) {
-    finish_bits<OUT2>(b0[0], b1[0]);
-    store_bits<OUT2>(out, (size_t)item, groups, blockIdx.y, b0[0], b1[0]);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const size_t pix = (size_t)img * OD * OD + (size_t)(2 * qy + (i >> 1)) * OD + 2 * qx + (i & 1);
-      finish_bits<OUT2>(b0[i], b1[i]);
-      store_bits<OUT2>(out, pix, groups, blockIdx.y, b0[i], b1[i]);
+  #pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const size_t pix = (size_t)img * OD * OD + (size_t)(2 * qy + (i >> 1)) * OD + 2 * qx + (i & 1);
+        finish_bits<OUT2>(b0[i], b1[i]);
+        store_bits<OUT2>(out, pix, groups, cg, b0[i], b1[i]);
+      }
     }
   }
 }
@@ -512,11 +542,12 @@ __global__ __launch_bounds__(kBlock) void k_quad(const uint64_t *__restrict__ in
 // and with SINGLE the 3x3 window gather of CNV layer 4).  Two neurons per iteration.
 template <int ARITH, int KW, bool OUT2, bool SINGLE, int CW, int ID>
 __global__ __launch_bounds__(kBlock) void k_vec(const uint64_t *__restrict__ in, uint32_t *__restrict__ out,
-                                                 const uint32_t *__restrict__ rows, int n_items) {
+                                                 const uint32_t *__restrict__ rows, int n_items, int groups, int gpb) {
   constexpr int PL = planes_in<ARITH>(), WPL = wplanes<ARITH>();
   constexpr int ROW_DW = 2 + 2 * KW * WPL, ZW = (PL == 2) ? KW : 1;
-  const int item = blockIdx.x * kBlock + threadIdx.x;
-  if (item >= n_items) return;
+  const BlockMap bm = map_block(groups / gpb, n_items);
+  if (!bm.valid) return;
+  const int item = bm.item;
   uint32_t as[KW][2], az[ZW][2];
   auto load_word = [&](int dst, const uint64_t *__restrict__ src) {
     const uint64_t v = src[0];
@@ -548,29 +579,31 @@ __global__ __launch_bounds__(kBlock) void k_vec(const uint64_t *__restrict__ in,
 #pragma unroll
     for (int k = 0; k < KW; k++) nn -= __builtin_popcount(az[k][0]) + __builtin_popcount(az[k][1]);
   }
-  kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)blockIdx.y * 32 * ROW_DW);
-  uint32_t b0 = 0, b1 = 0;
-  for (int c = 31; c >= 0; c -= 2) {
-    kptr32 rA = w + c * ROW_DW, rB = rA - ROW_DW;
-    int mA = 0, zA = 0, mB = 0, zB = 0;
-#pragma unroll
-    for (int k = 0; k < KW; k++)
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        mac32<ARITH>(mA, zA, as[k][h], az[PL == 2 ? k : 0][h], rA + 2 + 2 * WPL * k, h);
-        mac32<ARITH>(mB, zB, as[k][h], az[PL == 2 ? k : 0][h], rB + 2 + 2 * WPL * k, h);
+  for (int cg = bm.cg * gpb, cg_end = cg + gpb; cg < cg_end; cg++) {  // see k_conv0
+    kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)cg * 32 * ROW_DW);
+    uint32_t b0 = 0, b1 = 0;
+    for (int c = 31; c >= 0; c -= 2) {
+      kptr32 rA = w + c * ROW_DW, rB = rA - ROW_DW;
+      int mA = 0, zA = 0, mB = 0, zB = 0;
+  #pragma unroll
+      for (int k = 0; k < KW; k++)
+  #pragma unroll
+        for (int h = 0; h < 2; h++) {
+          mac32<ARITH>(mA, zA, as[k][h], az[PL == 2 ? k : 0][h], rA + 2 + 2 * WPL * k, h);
+          mac32<ARITH>(mB, zB, as[k][h], az[PL == 2 ? k : 0][h], rB + 2 + 2 * WPL * k, h);
+        }
+      const int tA0 = (int)rA[0], tA1 = (int)rA[1], tB0 = (int)rB[0], tB1 = (int)rB[1];
+      if constexpr (ARITH == AR_XNOR) {
+        decide<OUT2>(b0, b1, mA - tA0, tA0 - tA1);
+        decide<OUT2>(b0, b1, mB - tB0, tB0 - tB1);
+      } else {
+        decide<OUT2>(b0, b1, q_of<ARITH>(mA, zA, nn) + tA0, tA1 - tA0);
+        decide<OUT2>(b0, b1, q_of<ARITH>(mB, zB, nn) + tB0, tB1 - tB0);
       }
-    const int tA0 = (int)rA[0], tA1 = (int)rA[1], tB0 = (int)rB[0], tB1 = (int)rB[1];
-    if constexpr (ARITH == AR_XNOR) {
-      decide<OUT2>(b0, b1, mA - tA0, tA0 - tA1);
-      decide<OUT2>(b0, b1, mB - tB0, tB0 - tB1);
-    } else {
-      decide<OUT2>(b0, b1, q_of<ARITH>(mA, zA, nn) + tA0, tA1 - tA0);
-      decide<OUT2>(b0, b1, q_of<ARITH>(mB, zB, nn) + tB0, tB1 - tB0);
     }
+    finish_bits<OUT2>(b0, b1);
+    store_bits<OUT2>(out, (size_t)item, groups, cg, b0, b1);
   }
-  finish_bits<OUT2>(b0, b1);
-  store_bits<OUT2>(out, (size_t)item, gridDim.y, blockIdx.y, b0, b1);
 }
 
 // ---------------------------------------------------------------------------
@@ -656,7 +689,14 @@ __global__ __launch_bounds__(kBlock) void k_lfc_decode(const uint64_t *__restric
   classes[i] = w ? 63 - __builtin_clzll(w) : 0;
 }
 
-inline dim3 grid_for(long long items, int groups) { return dim3((unsigned)((items + kBlock - 1) / kBlock), (unsigned)groups); }
+// neuron groups per block: all of them once the work items alone fill the chip (256 CUs x 8 blocks),
+// so that a lane writes whole output words and reads its window once; otherwise one (parallelism first)
+inline int gpb_for(long long items, int groups) { return (items + kBlock - 1) / kBlock >= 2048 ? groups : 1; }
+
+inline dim3 grid_for(long long items, int groups) {  // matches map_block()
+  const long long item_blocks = (items + kBlock - 1) / kBlock;
+  return dim3((unsigned)(((item_blocks + 7) / 8) * 8 * groups));
+}
 
 #define BNN_LAUNCH(kern, grid, stream, ...)                                   \
   do {                                                                        \
@@ -675,37 +715,37 @@ void run_cnv_t(const CnvLaunch &a) {
   const uint64_t *A64 = reinterpret_cast<const uint64_t *>(a.buf0), *B64 = reinterpret_cast<const uint64_t *>(a.buf1);
   hipStream_t s = a.stream;
   BNN_MARK(a.events, 0, s);
-  BNN_LAUNCH((k_conv0<OUT2>), grid_for(n * 900, 2), s, a.images, A, a.rows[0], (int)(n * 900));
+  BNN_LAUNCH((k_conv0<OUT2>), grid_for(n * 900, 2 / gpb_for(n * 900, 2)), s, a.images, A, a.rows[0], (int)(n * 900), 2, gpb_for(n * 900, 2));
   BNN_MARK(a.events, 1, s);
   if constexpr (ARITH == AR_XNOR && !OUT2) {
-    BNN_LAUNCH((k_quad_x<1, 30, true>), grid_for(n * 196, 2), s, A64, B, a.rows[1], (int)(n * 196));
+    BNN_LAUNCH((k_quad_x<1, 30, true>), grid_for(n * 196, 2 / gpb_for(n * 196, 2)), s, A64, B, a.rows[1], (int)(n * 196), 2, gpb_for(n * 196, 2));
     BNN_MARK(a.events, 2, s);
-    BNN_LAUNCH((k_quad_x<1, 14, false>), grid_for(n * 36, 4), s, B64, A, a.rows[2], (int)(n * 36));
+    BNN_LAUNCH((k_quad_x<1, 14, false>), grid_for(n * 36, 4 / gpb_for(n * 36, 4)), s, B64, A, a.rows[2], (int)(n * 36), 4, gpb_for(n * 36, 4));
     BNN_MARK(a.events, 3, s);
-    BNN_LAUNCH((k_quad_x<2, 12, true>), grid_for(n * 25, 4), s, A64, B, a.rows[3], (int)(n * 25));
+    BNN_LAUNCH((k_quad_x<2, 12, true>), grid_for(n * 25, 4 / gpb_for(n * 25, 4)), s, A64, B, a.rows[3], (int)(n * 25), 4, gpb_for(n * 25, 4));
     BNN_MARK(a.events, 4, s);
-    BNN_LAUNCH((k_vec_x<18, true, 2, 5>), grid_for(n * 9, 8), s, B64, A, a.rows[4], (int)(n * 9));
+    BNN_LAUNCH((k_vec_x<18, true, 2, 5>), grid_for(n * 9, 8 / gpb_for(n * 9, 8)), s, B64, A, a.rows[4], (int)(n * 9), 8, gpb_for(n * 9, 8));
     BNN_MARK(a.events, 5, s);
-    BNN_LAUNCH((k_vec_x<36, false, 1, 1>), grid_for(n, 8), s, A64, B, a.rows[5], (int)n);
+    BNN_LAUNCH((k_vec_x<36, false, 1, 1>), grid_for(n, 8 / gpb_for(n, 8)), s, A64, B, a.rows[5], (int)n, 8, gpb_for(n, 8));
     BNN_MARK(a.events, 6, s);
-    BNN_LAUNCH((k_vec_x<4, false, 1, 1>), grid_for(n, 16), s, B64, A, a.rows[6], (int)n);
+    BNN_LAUNCH((k_vec_x<4, false, 1, 1>), grid_for(n, 16 / gpb_for(n, 16)), s, B64, A, a.rows[6], (int)n, 16, gpb_for(n, 16));
     BNN_MARK(a.events, 7, s);
-    BNN_LAUNCH((k_vec_x<8, false, 1, 1>), grid_for(n, 16), s, A64, B, a.rows[7], (int)n);
+    BNN_LAUNCH((k_vec_x<8, false, 1, 1>), grid_for(n, 16 / gpb_for(n, 16)), s, A64, B, a.rows[7], (int)n, 16, gpb_for(n, 16));
     BNN_MARK(a.events, 8, s);
   } else {
-  BNN_LAUNCH((k_quad<ARITH, 1, 30, true, OUT2>), grid_for(n * 196, 2), s, A64, B, a.rows[1], (int)(n * 196));
+  BNN_LAUNCH((k_quad<ARITH, 1, 30, true, OUT2>), grid_for(n * 196, 2 / gpb_for(n * 196, 2)), s, A64, B, a.rows[1], (int)(n * 196), 2, gpb_for(n * 196, 2));
   BNN_MARK(a.events, 2, s);
-  BNN_LAUNCH((k_quad<ARITH, 1, 14, false, OUT2>), grid_for(n * 36, 4), s, B64, A, a.rows[2], (int)(n * 36));
+  BNN_LAUNCH((k_quad<ARITH, 1, 14, false, OUT2>), grid_for(n * 36, 4 / gpb_for(n * 36, 4)), s, B64, A, a.rows[2], (int)(n * 36), 4, gpb_for(n * 36, 4));
   BNN_MARK(a.events, 3, s);
-  BNN_LAUNCH((k_quad<ARITH, 2, 12, true, OUT2>), grid_for(n * 25, 4), s, A64, B, a.rows[3], (int)(n * 25));
+  BNN_LAUNCH((k_quad<ARITH, 2, 12, true, OUT2>), grid_for(n * 25, 4 / gpb_for(n * 25, 4)), s, A64, B, a.rows[3], (int)(n * 25), 4, gpb_for(n * 25, 4));
   BNN_MARK(a.events, 4, s);
-  BNN_LAUNCH((k_vec<ARITH, 18, OUT2, true, 2, 5>), grid_for(n * 9, 8), s, B64, A, a.rows[4], (int)(n * 9));
+  BNN_LAUNCH((k_vec<ARITH, 18, OUT2, true, 2, 5>), grid_for(n * 9, 8 / gpb_for(n * 9, 8)), s, B64, A, a.rows[4], (int)(n * 9), 8, gpb_for(n * 9, 8));
   BNN_MARK(a.events, 5, s);
-  BNN_LAUNCH((k_vec<ARITH, 36, OUT2, false, 1, 1>), grid_for(n, 8), s, A64, B, a.rows[5], (int)n);
+  BNN_LAUNCH((k_vec<ARITH, 36, OUT2, false, 1, 1>), grid_for(n, 8 / gpb_for(n, 8)), s, A64, B, a.rows[5], (int)n, 8, gpb_for(n, 8));
   BNN_MARK(a.events, 6, s);
-  BNN_LAUNCH((k_vec<ARITH, 4, OUT2, false, 1, 1>), grid_for(n, 16), s, B64, A, a.rows[6], (int)n);
+  BNN_LAUNCH((k_vec<ARITH, 4, OUT2, false, 1, 1>), grid_for(n, 16 / gpb_for(n, 16)), s, B64, A, a.rows[6], (int)n, 16, gpb_for(n, 16));
   BNN_MARK(a.events, 7, s);
-  BNN_LAUNCH((k_vec<ARITH, 8, OUT2, false, 1, 1>), grid_for(n, 16), s, A64, B, a.rows[7], (int)n);
+  BNN_LAUNCH((k_vec<ARITH, 8, OUT2, false, 1, 1>), grid_for(n, 16 / gpb_for(n, 16)), s, A64, B, a.rows[7], (int)n, 16, gpb_for(n, 16));
   BNN_MARK(a.events, 8, s);
   }
   BNN_LAUNCH((k_fclast<ARITH, 8>), grid_for(n, 1), s, B64, a.scores, a.classes, a.rows[8], (int)n, a.number_class);
@@ -753,22 +793,22 @@ hipError_t run_lfc(NetId net, const LfcLaunch &a) {
   BNN_LAUNCH(k_lfc_binarize, grid_for(n * 13, 1), s, a.images, A64, (int)(n * 13));
   BNN_MARK(a.events, 1, s);
   if (net == NET_LFCW1A1) {
-    BNN_LAUNCH((k_vec_x<13, false, 1, 1>), grid_for(n, 32), s, A64, B, a.rows[0], (int)n);
+    BNN_LAUNCH((k_vec_x<13, false, 1, 1>), grid_for(n, 32 / gpb_for(n, 32)), s, A64, B, a.rows[0], (int)n, 32, gpb_for(n, 32));
     BNN_MARK(a.events, 2, s);
-    BNN_LAUNCH((k_vec_x<16, false, 1, 1>), grid_for(n, 32), s, B64, A, a.rows[1], (int)n);
+    BNN_LAUNCH((k_vec_x<16, false, 1, 1>), grid_for(n, 32 / gpb_for(n, 32)), s, B64, A, a.rows[1], (int)n, 32, gpb_for(n, 32));
     BNN_MARK(a.events, 3, s);
-    BNN_LAUNCH((k_vec_x<16, false, 1, 1>), grid_for(n, 32), s, A64, B, a.rows[2], (int)n);
+    BNN_LAUNCH((k_vec_x<16, false, 1, 1>), grid_for(n, 32 / gpb_for(n, 32)), s, A64, B, a.rows[2], (int)n, 32, gpb_for(n, 32));
     BNN_MARK(a.events, 4, s);
-    BNN_LAUNCH((k_vec_x<16, false, 1, 1>), grid_for(n, 2), s, B64, reinterpret_cast<uint32_t *>(a.words), a.rows[3], (int)n);
+    BNN_LAUNCH((k_vec_x<16, false, 1, 1>), grid_for(n, 2 / gpb_for(n, 2)), s, B64, reinterpret_cast<uint32_t *>(a.words), a.rows[3], (int)n, 2, gpb_for(n, 2));
     BNN_MARK(a.events, 5, s);
   } else if (net == NET_LFCW1A2) {
-    BNN_LAUNCH((k_vec<AR_XNOR, 13, true, false, 1, 1>), grid_for(n, 32), s, A64, B, a.rows[0], (int)n);
+    BNN_LAUNCH((k_vec<AR_XNOR, 13, true, false, 1, 1>), grid_for(n, 32 / gpb_for(n, 32)), s, A64, B, a.rows[0], (int)n, 32, gpb_for(n, 32));
     BNN_MARK(a.events, 2, s);
-    BNN_LAUNCH((k_vec<AR_TB, 16, true, false, 1, 1>), grid_for(n, 32), s, B64, A, a.rows[1], (int)n);
+    BNN_LAUNCH((k_vec<AR_TB, 16, true, false, 1, 1>), grid_for(n, 32 / gpb_for(n, 32)), s, B64, A, a.rows[1], (int)n, 32, gpb_for(n, 32));
     BNN_MARK(a.events, 3, s);
-    BNN_LAUNCH((k_vec<AR_TB, 16, true, false, 1, 1>), grid_for(n, 32), s, A64, B, a.rows[2], (int)n);
+    BNN_LAUNCH((k_vec<AR_TB, 16, true, false, 1, 1>), grid_for(n, 32 / gpb_for(n, 32)), s, A64, B, a.rows[2], (int)n, 32, gpb_for(n, 32));
     BNN_MARK(a.events, 4, s);
-    BNN_LAUNCH((k_vec<AR_TB, 16, false, false, 1, 1>), grid_for(n, 2), s, B64, reinterpret_cast<uint32_t *>(a.words), a.rows[3], (int)n);
+    BNN_LAUNCH((k_vec<AR_TB, 16, false, false, 1, 1>), grid_for(n, 2 / gpb_for(n, 2)), s, B64, reinterpret_cast<uint32_t *>(a.words), a.rows[3], (int)n, 2, gpb_for(n, 2));
     BNN_MARK(a.events, 5, s);
   } else {
     return hipErrorInvalidValue;

@@ -84,6 +84,28 @@ def test_batched_classes(network, dataset):
     assert got.tolist() == want.tolist()
 
 
+@pytest.mark.parametrize("network", ["cnvW1A1", "cnvW1A2", "cnvW2A2", "lfcW1A1", "lfcW1A2"])
+@pytest.mark.parametrize("seed", [3, 4])
+def test_random_params_bit_exact(network, seed, tmp_path):
+    """random weights/thresholds in the reference file format (unsorted threshold pairs, extremes):
+    every compare outcome of every layer gets exercised, not only what the trained nets hit"""
+    import random_params
+    random_params.make(str(tmp_path), network, seed)
+    L = gl.load(network)
+    L.load_parameters(str(tmp_path).encode())
+    assert L.bnn_mi355x_last_error() == b""
+    _nets.pop(network, None)                      # the cached Net of this library now holds other params
+    net = gl.Net.__new__(gl.Net)
+    net.L, net.network, net.is_cnv, net.isz = L, network, network.startswith("cnv"), L.bnn_mi355x_image_bytes()
+    n = 300 if net.is_cnv else 1500
+    imgs = rand_images(network, n, seed)
+    o = ol.Oracle(network, str(tmp_path))
+    ref = o.scores_fast(imgs) if o.is_cnv else o.words_fast(imgs)
+    got = net.raw(imgs)
+    assert (got == ref).all()
+    assert np.unique(ref).size > 8
+
+
 def test_detail_scores():
     ncls = 10
     imgs = rand_images("cnvW1A1", 77, 3)
@@ -148,6 +170,19 @@ def test_full_size_batch_properties():
     # the same image repeated gives the same scores wherever it sits in the batch
     rep = np.repeat(imgs[:1], 700, axis=0)
     assert (net.raw(rep) == s[0]).all()
+
+
+@pytest.mark.parametrize("network", ["cnvW1A1", "cnvW1A2", "cnvW2A2"])
+def test_large_batch_takes_the_wide_paths(network):
+    """>= 58 255 images: every stage switches to 'all neuron groups in one block' (gpb_for in
+    kernels.hip); seeded oracle sample + the small-batch result of the same images must agree"""
+    n = 60000
+    imgs = rand_images(network, n, 21)
+    net = gpu_net(network, "cifar10")
+    big = net.raw(imgs)
+    pick = np.random.default_rng(2).choice(n, 256, replace=False)
+    assert (oracle(network, "cifar10").scores_fast(imgs[pick]) == big[pick]).all()
+    assert (net.raw(imgs[:500]) == big[:500]).all()       # narrow path (500 images) == wide path
 
 
 def test_lfc_full_size_batch():
