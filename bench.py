@@ -172,7 +172,9 @@ def main():
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf):
         try:
-            traffic = json.load(open(tf)).get(a.network, {}).get("hbm_bytes_per_step")
+            t = json.load(open(tf)).get(a.network, {})
+            # measured HBM bytes per image (PMC passes, profiles/) x the images of one launch
+            traffic = int((t["fetch_bytes_per_image_x2"] + t["write_bytes_per_image"]) * imgs_per_launch)
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
