@@ -28,22 +28,22 @@ bool read_pe_file(const std::string &path, std::vector<uint64_t> &dst, size_t n)
 
 inline int32_t floor_div2(int32_t v) { return v >> 1; }  // arithmetic shift == floor for negatives
 
-// logical weight (value domain) of neuron n, column j, from the PE memories
-struct LayerFiles {
+// logical weight (value domain) of neuron n, column j, and threshold i of neuron n, from the PE memories
+struct LayerView {
   const LayerSpec *L;
-  std::vector<std::vector<uint64_t>> w, t;  // per PE
+  const std::vector<std::vector<uint64_t>> *w, *t;  // per PE
   int weight(int n, int j) const {
     const int pe = n % L->fold.pe, nf = n / L->fold.pe;
     const int sf_count = L->fold.wmem / L->fold.tmem;
     const int sf = j / L->fold.simd, s = j % L->fold.simd;
-    const uint64_t word = w[pe][(size_t)nf * sf_count + sf];
+    const uint64_t word = (*w)[pe][(size_t)nf * sf_count + sf];
     if (L->wbits == 1) return ((word >> s) & 1) ? 1 : -1;
     const int f = (int)((word >> (2 * s)) & 3);  // ap_int<2>
     return f >= 2 ? f - 4 : f;
   }
   int32_t threshold(int n, int i) const {
     const int pe = n % L->fold.pe, nf = n / L->fold.pe;
-    const uint64_t e = t[pe][(size_t)nf * L->nthr + i];
+    const uint64_t e = (*t)[pe][(size_t)nf * L->nthr + i];
     if (L->thr24) {  // ap_fixed<64,56> bits assigned to ap_fixed<24,16>: low 24 bits, sign-extended
       int32_t v = (int32_t)(e & 0xFFFFFF);
       return (v & 0x800000) ? v - 0x1000000 : v;
@@ -51,6 +51,63 @@ struct LayerFiles {
     return (int16_t)(e & 0xFFFF);  // ap_uint<64> assigned to ap_int<16>
   }
 };
+
+void fill_row(const LayerSpec &L, const LayerView &F, int n, uint32_t *row, uint32_t rd) {
+  const int MW = L.mw();
+  for (uint32_t i = 0; i < rd; i++) row[i] = 0;
+  int32_t T[2] = {0, 0};
+  for (int i = 0; i < L.nthr && i < 2; i++) T[i] = F.threshold(n, i);
+  if (L.nthr == 1) T[1] = T[0];
+  for (int i = 0; i < 2; i++) {
+    int32_t t;
+    if (L.arith == AR_INT8) t = floor_div2(T[i]);
+    else if (L.arith == AR_XNOR) t = L.signed_bb ? floor_div2(MW - T[i] + 1) : (MW - T[i]);
+    else t = T[i];
+    row[i] = (uint32_t)t;
+  }
+  if (L.arith == AR_INT8) {
+    // tap tau = 3*(c*3+ky) + kx  <->  reference column (ky*3+kx)*3 + c
+    for (int c = 0; c < 3; c++)
+      for (int ky = 0; ky < 3; ky++)
+        for (int kx = 0; kx < 3; kx++) {
+          const int tau = 3 * (c * 3 + ky) + kx;
+          const int wv = F.weight(n, (ky * 3 + kx) * 3 + c);
+          row[2 + tau / 4] |= (uint32_t)(uint8_t)(int8_t)wv << (8 * (tau % 4));
+        }
+  } else {
+    uint64_t *wq = reinterpret_cast<uint64_t *>(row + 2);
+    const int kw = MW / 64;
+    for (int k = 0; k < kw; k++) {
+      uint64_t pos = 0, neg = 0, nz = 0;
+      for (int b = 0; b < 64; b++) {
+        const int wv = F.weight(n, k * 64 + b);
+        if (wv > 0) pos |= 1ull << b;
+        if (wv < 0) neg |= 1ull << b;
+        if (wv != 0) nz |= 1ull << b;
+      }
+      if (L.arith == AR_XNOR) wq[k] = pos;
+      else if (L.arith == AR_TB) wq[k] = neg;
+      else { wq[2 * k] = neg; wq[2 * k + 1] = nz; }
+    }
+  }
+}
+
+void layout_header(const NetSpec &net, PackedHeader &h) {
+  h = PackedHeader{};
+  h.magic0 = kBlobMagic0; h.magic1 = kBlobMagic1; h.version = kBlobVersion;
+  h.net_id = (uint32_t)net.id; h.nlayers = (uint32_t)net.nlayers;
+  uint32_t off = (sizeof(PackedHeader) + 255u) & ~255u;
+  for (int l = 0; l < net.nlayers; l++) {
+    const LayerSpec &L = net.L[l];
+    h.layer[l].offset = off;
+    h.layer[l].row_dwords = row_dwords_for(L);
+    h.layer[l].rows = (uint32_t)L.mh();
+    h.layer[l].kw = (L.arith == AR_INT8) ? 0 : (uint32_t)L.mw() / 64;
+    off += h.layer[l].row_dwords * 4 * h.layer[l].rows;
+    off = (off + 255u) & ~255u;
+  }
+  h.total_bytes = off + 256;  // tail slack: wide scalar loads may run past the last row
+}
 
 }  // namespace
 
@@ -65,82 +122,54 @@ uint32_t row_dwords_for(const LayerSpec &L) {
   return 0;
 }
 
-std::string pack_params_from_dir(const NetSpec &net, const std::string &dir, std::vector<uint8_t> &blob) {
-  PackedHeader h{};
-  h.magic0 = kBlobMagic0; h.magic1 = kBlobMagic1; h.version = kBlobVersion;
-  h.net_id = (uint32_t)net.id; h.nlayers = (uint32_t)net.nlayers;
-  uint32_t off = (sizeof(PackedHeader) + 255u) & ~255u;
+std::string read_raw_params(const NetSpec &net, const std::string &dir, RawParams &raw) {
   for (int l = 0; l < net.nlayers; l++) {
     const LayerSpec &L = net.L[l];
-    h.layer[l].offset = off;
-    h.layer[l].row_dwords = row_dwords_for(L);
-    h.layer[l].rows = (uint32_t)L.mh();
-    h.layer[l].kw = (L.arith == AR_INT8) ? 0 : (uint32_t)L.mw() / 64;
-    off += h.layer[l].row_dwords * 4 * h.layer[l].rows;
-    off = (off + 255u) & ~255u;
-  }
-  h.total_bytes = off + 256;  // tail slack: wide scalar loads may run past the last row
-  blob.assign(h.total_bytes, 0);
-  std::memcpy(blob.data(), &h, sizeof(h));
-
-  for (int l = 0; l < net.nlayers; l++) {
-    const LayerSpec &L = net.L[l];
-    LayerFiles F;
-    F.L = &L;
-    F.w.resize(L.fold.pe);
-    F.t.resize(L.fold.pe);
+    raw.w[l].assign(L.fold.pe, {});
+    raw.t[l].assign(L.fold.pe, {});
     for (int pe = 0; pe < L.fold.pe; pe++) {
       const std::string stem = dir + "/" + std::to_string(l) + "-" + std::to_string(pe);
-      if (!read_pe_file(stem + "-weights.bin", F.w[pe], (size_t)L.fold.wmem))
+      if (!read_pe_file(stem + "-weights.bin", raw.w[l][pe], (size_t)L.fold.wmem))
         return "Could not open file " + stem + "-weights.bin";
-      if (L.nthr > 0 && !read_pe_file(stem + "-thres.bin", F.t[pe], (size_t)L.fold.tmem * L.nthr))
+      if (L.nthr > 0 && !read_pe_file(stem + "-thres.bin", raw.t[l][pe], (size_t)L.fold.tmem * L.nthr))
         return "Could not open file " + stem + "-thres.bin";
     }
-    const int MW = L.mw(), MH = L.mh();
+  }
+  return "";
+}
+
+void pack_blob(const NetSpec &net, const RawParams &raw, std::vector<uint8_t> &blob) {
+  PackedHeader h;
+  layout_header(net, h);
+  blob.assign(h.total_bytes, 0);
+  std::memcpy(blob.data(), &h, sizeof(h));
+  for (int l = 0; l < net.nlayers; l++) {
+    const LayerSpec &L = net.L[l];
+    const LayerView F{&L, &raw.w[l], &raw.t[l]};
     const uint32_t rd = h.layer[l].row_dwords;
     uint32_t *rows = reinterpret_cast<uint32_t *>(blob.data() + h.layer[l].offset);
-    for (int n = 0; n < MH; n++) {
-      uint32_t *row = rows + (size_t)n * rd;
-      // thresholds
-      int32_t T[2] = {0, 0};
-      for (int i = 0; i < L.nthr && i < 2; i++) T[i] = F.threshold(n, i);
-      if (L.nthr == 1) T[1] = T[0];
-      int32_t t[2];
-      for (int i = 0; i < 2; i++) {
-        if (L.arith == AR_INT8) t[i] = floor_div2(T[i]);
-        else if (L.arith == AR_XNOR) t[i] = L.signed_bb ? floor_div2(MW - T[i] + 1) : (MW - T[i]);
-        else t[i] = T[i];
-      }
-      row[0] = (uint32_t)t[0];
-      row[1] = (uint32_t)t[1];
-      // weights
-      if (L.arith == AR_INT8) {
-        // tap tau = 3*(c*3+ky) + kx  <->  reference column (ky*3+kx)*3 + c
-        for (int c = 0; c < 3; c++)
-          for (int ky = 0; ky < 3; ky++)
-            for (int kx = 0; kx < 3; kx++) {
-              const int tau = 3 * (c * 3 + ky) + kx;
-              const int wv = F.weight(n, (ky * 3 + kx) * 3 + c);
-              row[2 + tau / 4] |= (uint32_t)(uint8_t)(int8_t)wv << (8 * (tau % 4));
-            }
-      } else {
-        uint64_t *wq = reinterpret_cast<uint64_t *>(row + 2);
-        const int kw = MW / 64;
-        for (int k = 0; k < kw; k++) {
-          uint64_t pos = 0, neg = 0, nz = 0;
-          for (int b = 0; b < 64; b++) {
-            const int wv = F.weight(n, k * 64 + b);
-            if (wv > 0) pos |= 1ull << b;
-            if (wv < 0) neg |= 1ull << b;
-            if (wv != 0) nz |= 1ull << b;
-          }
-          if (L.arith == AR_XNOR) wq[k] = pos;
-          else if (L.arith == AR_TB) wq[k] = neg;
-          else { wq[2 * k] = neg; wq[2 * k + 1] = nz; }
-        }
-      }
-    }
+    for (int n = 0; n < L.mh(); n++) fill_row(L, F, n, rows + (size_t)n * rd, rd);
   }
+}
+
+void repack_row(const NetSpec &net, const RawParams &raw, int l, int n, std::vector<uint8_t> &blob, size_t *offset,
+                size_t *bytes) {
+  PackedHeader h;
+  std::memcpy(&h, blob.data(), sizeof(h));
+  const LayerSpec &L = net.L[l];
+  const LayerView F{&L, &raw.w[l], &raw.t[l]};
+  const uint32_t rd = h.layer[l].row_dwords;
+  const size_t off = h.layer[l].offset + (size_t)n * rd * 4;
+  fill_row(L, F, n, reinterpret_cast<uint32_t *>(blob.data() + off), rd);
+  *offset = off;
+  *bytes = (size_t)rd * 4;
+}
+
+std::string pack_params_from_dir(const NetSpec &net, const std::string &dir, std::vector<uint8_t> &blob) {
+  RawParams raw;
+  const std::string e = read_raw_params(net, dir, raw);
+  if (!e.empty()) return e;
+  pack_blob(net, raw, blob);
   return "";
 }
 

@@ -62,6 +62,21 @@ static_assert(sizeof(PackedHeader) == 32 + 9 * 16, "blob header layout");
 
 uint32_t row_dwords_for(const LayerSpec &L);
 
+// The reference's PE memories exactly as the files hold them (what DoMemInit / DoMemRead see,
+// top.cpp:78-178): per layer, per PE, WMEM weight words and TMEM*nThr threshold words.  Kept on the
+// host next to the blob so that single words can be modified (fault injection,
+// FoldedMVMemRead/FoldedMVMemSet, foldedmv-offload.h:146-214) and the affected blob row rebuilt.
+struct RawParams {
+  std::vector<std::vector<uint64_t>> w[9], t[9];
+  bool empty() const { return w[0].empty(); }
+};
+
+std::string read_raw_params(const NetSpec &net, const std::string &dir, RawParams &raw);
+void pack_blob(const NetSpec &net, const RawParams &raw, std::vector<uint8_t> &blob);
+// rebuild row n of layer l inside an existing blob; returns the byte offset and size of that row
+void repack_row(const NetSpec &net, const RawParams &raw, int l, int n, std::vector<uint8_t> &blob, size_t *offset,
+                size_t *bytes);
+
 // Reads the param directory and fills `blob`.  Returns "" on success, else the
 // error text (missing file: the reference throws "Could not open file",
 // foldedmv-offload.cpp:321-323).  Short files are zero-filled like the

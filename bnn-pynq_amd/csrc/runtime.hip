@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "../../include/bnn_mi355x.h"
+#include "faults.h"
 #include "kernels.h"
 #include "packed_params.h"
 #include "topology.h"
@@ -42,8 +43,11 @@ struct Runtime {
   int device = -1;  // -1: whatever HIP's current device is
   std::string err;
   // parameters
+  RawParams raw;  // the reference-layout memories (empty when the blob was imported)
   std::vector<uint8_t> blob;
   void *d_blob = nullptr;
+  uint64_t fault_seed = 0;  // 0: std::random_device, like the reference
+  std::vector<Fault> last_faults;
   const uint32_t *rows[9] = {};
   // workspace
   int cap = 0;
@@ -292,10 +296,11 @@ extern "C" {
 void load_parameters(const char *path) {
   Runtime &r = rt();
   std::printf("Setting network weights and thresholds in accelerator...\n");
-  std::vector<uint8_t> blob;
-  const std::string e = pack_params_from_dir(r.spec, path ? path : "", blob);
+  RawParams raw;
+  const std::string e = read_raw_params(r.spec, path ? path : "", raw);
   if (!e.empty()) { fail(e); return; }
-  r.blob.swap(blob);
+  r.raw = std::move(raw);
+  pack_blob(r.spec, r.raw, r.blob);
   if (upload_blob()) { r.blob.clear(); return; }
   r.err.clear();
 }
@@ -351,13 +356,60 @@ int *inference_multiple(const char *path, int number_class, int *image_number, f
 int *inference_multiple_with_faults(const char *path, int number_class, int *image_number,
                                     float *usecPerImage, unsigned int flip_count, int word_size,
                                     int target, int *target_layers, unsigned int num_targets) {
-  (void)word_size; (void)target; (void)target_layers; (void)num_targets;
-  if (flip_count != 0) {
-    fail("fault injection (flip_count > 0) is not available in the MI355X runtime");
-    if (image_number) *image_number = 0;
+  Runtime &r = rt();
+  if (flip_count == 0) return inference_multiple(path, number_class, image_number, usecPerImage, 0);
+  if (!ready()) return nullptr;
+  if (r.raw.empty()) {
+    fail("fault injection needs the parameter files (load_parameters), not an imported blob");
     return nullptr;
   }
-  return inference_multiple(path, number_class, image_number, usecPerImage, 0);
+  std::vector<uint8_t> imgs;
+  const int n = read_images(path, imgs);
+  if (n < 0) return nullptr;
+  // The reference classifies image by image and injects each fault just before the image it was
+  // drawn for (faults.h:115-148).  Same result, fewer launches: classify the run of images between
+  // two fault times as one batch, then patch the affected rows in HBM.
+  r.last_faults = plan_faults(r.spec, r.fault_seed, n, flip_count, word_size, target, target_layers, num_targets);
+  int *result = new (std::nothrow) int[(size_t)(n > 0 ? n : 1)];
+  if (!result) { fail("out of memory"); return nullptr; }
+  const size_t isz = (size_t)r.spec.image_bytes();
+  double total_us = 0.0;
+  size_t k = 0;
+  int start = 0;
+  while (start < n) {
+    while (k < r.last_faults.size() && r.last_faults[k].image <= start) {
+      const Fault &f = r.last_faults[k++];
+      const int row = apply_fault(r.spec, r.raw, f);
+      if (row < 0) continue;
+      size_t off = 0, bytes = 0;
+      repack_row(r.spec, r.raw, f.layer, row, r.blob, &off, &bytes);
+      if (hipMemcpy(static_cast<uint8_t *>(r.d_blob) + off, r.blob.data() + off, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        fail("hipMemcpy of a patched parameter row failed");
+        delete[] result;
+        return nullptr;
+      }
+    }
+    const int end = (k < r.last_faults.size()) ? r.last_faults[k].image : n;
+    const int m = end - start;
+    float usec = 0.f;
+    int rc;
+    if (r.spec.is_cnv) {
+      rc = infer_host(imgs.data() + (size_t)start * isz, m, number_class, result + start, nullptr, nullptr, &usec);
+    } else {
+      std::vector<uint64_t> w((size_t)m);
+      rc = infer_host(imgs.data() + (size_t)start * isz, m, number_class, nullptr, nullptr, w.data(), &usec);
+      for (int i = 0; rc == 0 && i < m; i++) result[start + i] = lfc_class_batched(w[i], number_class);
+    }
+    if (rc) { delete[] result; return nullptr; }
+    total_us += (double)usec * m;
+    start = end;
+  }
+  const float usec = n > 0 ? (float)(total_us / n) : 0.f;
+  std::printf("Inference took %.0f microseconds, %g usec per image\n", total_us, usec);
+  std::printf("Classification rate: %g images per second\n", 1000000.0 / usec);
+  if (image_number) *image_number = n;
+  if (usecPerImage) *usecPerImage = usec;
+  return result;
 }
 
 void free_results(int *result) { delete[] result; }
@@ -401,6 +453,7 @@ int bnn_mi355x_import_params(const void *src, size_t bytes) {
   const std::string e = validate_blob(r.spec, src, bytes);
   if (!e.empty()) return fail(e);
   r.blob.assign(static_cast<const uint8_t *>(src), static_cast<const uint8_t *>(src) + bytes);
+  r.raw = RawParams{};
   if (upload_blob()) { r.blob.clear(); return -1; }
   r.err.clear();
   return 0;
@@ -421,6 +474,51 @@ int bnn_mi355x_inference_raw(const uint8_t *images, int n_images, int16_t *score
 }
 
 int bnn_mi355x_reserve(int max_images) { return ready() ? reserve(max_images) : -1; }
+
+int bnn_mi355x_plan_faults(unsigned long long seed, int num_images, unsigned int flip_count, int word_size, int target,
+                           const int *target_layers, unsigned int num_targets, int *records, int cap_records) {
+  const std::vector<Fault> plan = plan_faults(rt().spec, seed, num_images, flip_count, word_size, target, target_layers, num_targets);
+  for (size_t i = 0; i < plan.size() && (int)i < cap_records; i++) {
+    const Fault &f = plan[i];
+    const int v[8] = {f.image, f.target, f.layer, f.mem, f.ind, f.thresh, f.bit, f.word_size};
+    for (int j = 0; j < 8; j++) records[i * 8 + j] = v[j];
+  }
+  return (int)plan.size();
+}
+
+size_t bnn_mi355x_pack_params_faulty(const char *path, const int *records, int n_faults, void *dst, size_t cap) {
+  RawParams raw;
+  const std::string e = read_raw_params(rt().spec, path ? path : "", raw);
+  if (!e.empty()) { fail(e); return 0; }
+  for (int i = 0; i < n_faults; i++) {
+    const int *v = records + i * 8;
+    const Fault f{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+    if (apply_fault(rt().spec, raw, f) < 0) { fail("pack_params_faulty: fault record out of range"); return 0; }
+  }
+  std::vector<uint8_t> blob;
+  pack_blob(rt().spec, raw, blob);
+  if (dst) {
+    if (cap < blob.size()) { fail("pack_params_faulty: destination too small"); return 0; }
+    std::memcpy(dst, blob.data(), blob.size());
+  }
+  return blob.size();
+}
+
+int bnn_mi355x_set_fault_seed(unsigned long long seed) {
+  rt().fault_seed = seed;
+  return 0;
+}
+
+int bnn_mi355x_last_faults(int *records, int cap_records) {
+  Runtime &r = rt();
+  const int n = (int)r.last_faults.size();
+  for (int i = 0; i < n && i < cap_records; i++) {
+    const Fault &f = r.last_faults[i];
+    const int v[8] = {f.image, f.target, f.layer, f.mem, f.ind, f.thresh, f.bit, f.word_size};
+    for (int j = 0; j < 8; j++) records[i * 8 + j] = v[j];
+  }
+  return n;
+}
 
 int bnn_mi355x_profile(int enable) {
   Runtime &r = rt();

@@ -56,8 +56,13 @@ int *inference_multiple(const char *path, int number_class, int *image_number, f
 
 /* Replaces inference_multiple_with_faults (main_python.cpp:171-223).
  * flip_count == 0: classifies like inference_multiple(enable_detail = 0).
- * flip_count > 0: not available (the reference draws fault positions from
- * std::random_device, faults.h:115-148); prints a message and returns NULL. */
+ * flip_count > 0: flip_count faults (word_size adjacent bits of one weight or
+ * threshold memory word; target < 0 any, 0 weights, > 0 thresholds; optional
+ * list of target layers) at uniformly drawn image indices and memory positions,
+ * selection weighted by memory size, addressed and applied exactly like
+ * inject_fault / inject_fault_impl (foldedmv-offload.h:146-214).  Faults stay in
+ * the loaded parameters until the next load_parameters.  The reference seeds
+ * from std::random_device; see bnn_mi355x_set_fault_seed. */
 int *inference_multiple_with_faults(const char *path, int number_class, int *image_number,
                                     float *usecPerImage, unsigned int flip_count, int word_size,
                                     int target, int *target_layers, unsigned int num_targets);
@@ -113,6 +118,19 @@ int bnn_mi355x_inference_raw(const uint8_t *images, int n_images, int16_t *score
 int bnn_mi355x_inference_device(const void *d_images, int n_images, int number_class, int32_t *d_classes,
                                 int16_t *d_scores, uint64_t *d_words, void *hip_stream);
 int bnn_mi355x_reserve(int max_images);
+
+/* Fault campaigns: fix the seed of the fault planner (0 = std::random_device like the
+ * reference, the default) and read back the faults of the last
+ * inference_multiple_with_faults call as records of 8 ints
+ * {image, target (0 weights / 1 thresholds), layer, mem (PE), ind, thresh, bit, word_size};
+ * returns the number of faults. */
+int bnn_mi355x_set_fault_seed(unsigned long long seed);
+int bnn_mi355x_last_faults(int *records, int cap_records);
+/* Host-only helpers of the same machinery (no GPU touched): draw a fault plan; pack a parameter
+ * directory with a list of fault records applied (what the GPU holds after those faults). */
+int bnn_mi355x_plan_faults(unsigned long long seed, int num_images, unsigned int flip_count, int word_size, int target,
+                           const int *target_layers, unsigned int num_targets, int *records, int cap_records);
+size_t bnn_mi355x_pack_params_faulty(const char *path, const int *records, int n_faults, void *dst, size_t cap);
 
 /* Per-stage device timing with HIP events on the stream the kernels run on
  * (used by bench.py for the roofline line).  profile(1) makes every later

@@ -56,6 +56,9 @@ struct bnn_oracle {
   /* fast path: bit planes, [mh][kw] */
   uint64_t *Wp[9];  /* 1-bit: bit=1 <=> +1 ; 2-bit: sign plane (bit=1 <=> -1) */
   uint64_t *Wn[9];  /* 2-bit: non-zero plane */
+  /* the PE memories as the files hold them, [pe][wmem] / [pe][tmem*nthr] (DoMemInit's targets,
+   * top.cpp:78-135): kept so that single words can be modified (fault injection) */
+  uint64_t *wraw[9], *traw[9];
 };
 
 /* --------------------------------------------------------------------------
@@ -166,82 +169,120 @@ static int read_words(const char *path, uint64_t *dst, size_t n) {
   return 0;
 }
 
+/* decode row n of layer l from the raw PE memories into W / T / bit planes */
+static void derive_row(bnn_oracle *o, int l, int n) {
+  lcfg *L = &o->L[l];
+  const int SF = L->wmem / L->tmem, kw = (L->mw + 63) / 64;
+  const int p = n % L->pe, nf = n / L->pe;
+  const uint64_t *wf = o->wraw[l] + (size_t)p * L->wmem;
+  for (int sf = 0; sf < SF; sf++) {
+    const uint64_t word = wf[nf * SF + sf];
+    for (int s = 0; s < L->simd; s++) {
+      int v;
+      if (L->wbits == 1) {
+        /* BinaryWeights + Recast<Binary>/XnorMul: bit 1 <=> +1 */
+        v = ((word >> s) & 1) ? 1 : -1;
+      } else {
+        /* FixedPointWeights<.., ap_int<2>, ..> (cnvW2A2/hw/top.cpp:52-60) */
+        const int f = (int)((word >> (2 * s)) & 3);
+        v = (f >= 2) ? f - 4 : f;
+      }
+      o->W[l][(size_t)n * L->mw + sf * L->simd + s] = (int8_t)v;
+    }
+  }
+  for (int i = 0; i < L->nthr; i++) {
+    const uint64_t e = o->traw[l][(size_t)p * L->tmem * L->nthr + nf * L->nthr + i];
+    int32_t t;
+    if (L->thr24) {
+      /* top.cpp:84: reinterpret as ap_fixed<64,56>, assign to
+       * ap_fixed<24,16> (AP_TRN, AP_WRAP): low 24 bits, units of 2^-8 */
+      t = (int32_t)(e & 0xFFFFFF);
+      if (t & 0x800000) t -= 0x1000000;
+    } else {
+      /* top.cpp:90: ap_uint<64> -> ap_int<16>: low 16 bits */
+      t = (int16_t)(e & 0xFFFF);
+    }
+    o->T[l][n * 2 + i] = t;
+  }
+  for (int k = 0; k < kw; k++) o->Wp[l][(size_t)n * kw + k] = o->Wn[l][(size_t)n * kw + k] = 0;
+  for (int j = 0; j < L->mw; j++) {
+    const int v = o->W[l][(size_t)n * L->mw + j];
+    const uint64_t b = (uint64_t)1 << (j & 63);
+    if (L->xnor) {
+      if (v > 0) o->Wp[l][(size_t)n * kw + j / 64] |= b;
+    } else {
+      if (v < 0) o->Wp[l][(size_t)n * kw + j / 64] |= b; /* sign plane */
+      if (v != 0) o->Wn[l][(size_t)n * kw + j / 64] |= b;
+    }
+  }
+}
+
 static int load_layer(bnn_oracle *o, const char *dir, int l) {
   lcfg *L = &o->L[l];
-  const int SF = L->wmem / L->tmem;
+  const int kw = (L->mw + 63) / 64;
   char path[4096];
-  uint64_t *wf = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)L->wmem);
-  uint64_t *tf = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)L->tmem * 2);
+  o->wraw[l] = (uint64_t *)calloc((size_t)L->pe * L->wmem, 8);
+  o->traw[l] = (uint64_t *)calloc((size_t)L->pe * L->tmem * 2 + 1, 8);
   o->W[l] = (int8_t *)calloc((size_t)L->mh * L->mw, 1);
   o->T[l] = (int32_t *)calloc((size_t)L->mh * 2, sizeof(int32_t));
+  o->Wp[l] = (uint64_t *)calloc((size_t)L->mh * kw, 8);
+  o->Wn[l] = (uint64_t *)calloc((size_t)L->mh * kw, 8);
   for (int p = 0; p < L->pe; p++) {
     snprintf(path, sizeof(path), "%s/%d-%d-weights.bin", dir, l, p);
-    if (read_words(path, wf, (size_t)L->wmem)) {
+    if (read_words(path, o->wraw[l] + (size_t)p * L->wmem, (size_t)L->wmem)) {
       fprintf(stderr, "bnn_oracle: Could not open file %s\n", path);
-      free(wf); free(tf);
       return -1;
     }
     if (L->nthr > 0) {
       snprintf(path, sizeof(path), "%s/%d-%d-thres.bin", dir, l, p);
-      if (read_words(path, tf, (size_t)L->tmem * L->nthr)) {
+      if (read_words(path, o->traw[l] + (size_t)p * L->tmem * L->nthr, (size_t)L->tmem * L->nthr)) {
         fprintf(stderr, "bnn_oracle: Could not open file %s\n", path);
-        free(wf); free(tf);
         return -1;
       }
     }
-    for (int nf = 0; nf < L->tmem; nf++) {
-      const int n = nf * L->pe + p;
-      for (int sf = 0; sf < SF; sf++) {
-        const uint64_t word = wf[nf * SF + sf];
-        for (int s = 0; s < L->simd; s++) {
-          int v;
-          if (L->wbits == 1) {
-            /* BinaryWeights + Recast<Binary>/XnorMul: bit 1 <=> +1 */
-            v = ((word >> s) & 1) ? 1 : -1;
-          } else {
-            /* FixedPointWeights<.., ap_int<2>, ..> (cnvW2A2/hw/top.cpp:52-60) */
-            const int f = (int)((word >> (2 * s)) & 3);
-            v = (f >= 2) ? f - 4 : f;
-          }
-          o->W[l][(size_t)n * L->mw + sf * L->simd + s] = (int8_t)v;
-        }
-      }
-      for (int i = 0; i < L->nthr; i++) {
-        const uint64_t e = tf[nf * L->nthr + i];
-        int32_t t;
-        if (L->thr24) {
-          /* top.cpp:84: reinterpret as ap_fixed<64,56>, assign to
-           * ap_fixed<24,16> (AP_TRN, AP_WRAP): low 24 bits, units of 2^-8 */
-          t = (int32_t)(e & 0xFFFFFF);
-          if (t & 0x800000) t -= 0x1000000;
-        } else {
-          /* top.cpp:90: ap_uint<64> -> ap_int<16>: low 16 bits */
-          t = (int16_t)(e & 0xFFFF);
-        }
-        o->T[l][n * 2 + i] = t;
-      }
-    }
   }
-  free(wf); free(tf);
+  for (int n = 0; n < L->mh; n++) derive_row(o, l, n);
   return 0;
 }
 
-static void build_planes(bnn_oracle *o, int l) {
-  lcfg *L = &o->L[l];
-  const int kw = (L->mw + 63) / 64;
-  o->Wp[l] = (uint64_t *)calloc((size_t)L->mh * kw, 8);
-  o->Wn[l] = (uint64_t *)calloc((size_t)L->mh * kw, 8);
-  for (int n = 0; n < L->mh; n++)
-    for (int j = 0; j < L->mw; j++) {
-      const int v = o->W[l][(size_t)n * L->mw + j];
-      const uint64_t b = (uint64_t)1 << (j & 63);
-      if (L->xnor) {
-        if (v > 0) o->Wp[l][(size_t)n * kw + j / 64] |= b;
-      } else {
-        if (v < 0) o->Wp[l][(size_t)n * kw + j / 64] |= b; /* sign plane */
-        if (v != 0) o->Wn[l][(size_t)n * kw + j / 64] |= b;
-      }
+/* --------------------------------------------------------------------------
+ * Fault injection on one memory word: inject_fault_impl (foldedmv-offload.h:146-163) through
+ * FoldedMVMemRead / FoldedMVMemSet -> DoMemRead / DoMemInit (top.cpp:78-178).
+ * target 0: weight memory word (layer, mem = PE, ind); 1: threshold (layer, mem, ind, thresh).
+ * bit_pos is aligned down to a multiple of word_size, word_size adjacent bits are flipped.
+ * -------------------------------------------------------------------------- */
+int bnn_oracle_apply_fault(bnn_oracle *o, int target, int layer, int mem, int ind, int thresh, int bit_pos,
+                           int word_size) {
+  if (layer < 0 || layer >= o->nl || word_size < 1 || word_size > 64) return -1;
+  lcfg *L = &o->L[layer];
+  uint64_t flip = (word_size >= 64) ? ~(uint64_t)0 : (((uint64_t)1 << word_size) - 1);
+  flip <<= (bit_pos / word_size) * word_size;
+  int n;
+  if (target == 0) {
+    if (mem >= L->pe || ind >= L->wmem) return -1;
+    const int ebits = L->simd * L->wbits; /* m_weights is ap_uint<SIMD*WPI> */
+    const uint64_t emask = (ebits >= 64) ? ~(uint64_t)0 : (((uint64_t)1 << ebits) - 1);
+    uint64_t *w = &o->wraw[layer][(size_t)mem * L->wmem + ind];
+    *w = ((*w & emask) ^ flip) & emask;
+    n = (ind / (L->wmem / L->tmem)) * L->pe + mem;
+  } else {
+    if (L->nthr == 0 || mem >= L->pe || ind >= L->tmem || thresh >= L->nthr) return -1;
+    uint64_t *t = &o->traw[layer][(size_t)mem * L->tmem * L->nthr + (size_t)ind * L->nthr + thresh];
+    int64_t v;
+    if (L->thr24) {
+      /* DoMemRead: static_cast<ap_uint<64>>(ap_fixed<24,16>) = the INTEGER part (top.cpp:143);
+       * DoMemInit then reinterprets the word as ap_fixed<64,56> (top.cpp:84) */
+      int32_t t24 = (int32_t)(*t & 0xFFFFFF);
+      if (t24 & 0x800000) t24 -= 0x1000000;
+      v = (int64_t)(t24 >> 8);
+    } else {
+      v = (int64_t)(int16_t)(*t & 0xFFFF);
     }
+    *t = (uint64_t)v ^ flip;
+    n = ind * L->pe + mem;
+  }
+  derive_row(o, layer, n);
+  return n;
 }
 
 bnn_oracle *bnn_oracle_create(const char *network, const char *param_dir) {
@@ -256,7 +297,6 @@ bnn_oracle *bnn_oracle_create(const char *network, const char *param_dir) {
       bnn_oracle_destroy(o);
       return NULL;
     }
-    build_planes(o, l);
   }
   return o;
 }
@@ -264,7 +304,7 @@ bnn_oracle *bnn_oracle_create(const char *network, const char *param_dir) {
 void bnn_oracle_destroy(bnn_oracle *o) {
   if (!o) return;
   for (int l = 0; l < 9; l++) {
-    free(o->W[l]); free(o->T[l]); free(o->Wp[l]); free(o->Wn[l]);
+    free(o->W[l]); free(o->T[l]); free(o->Wp[l]); free(o->Wn[l]); free(o->wraw[l]); free(o->traw[l]);
   }
   free(o);
 }

@@ -80,6 +80,13 @@ int bnn_oracle_parse_cifar10(const char *path, uint8_t **out);
 int bnn_oracle_parse_mnist(const char *path, uint8_t **out);
 void bnn_oracle_free(void *p);
 
+/* ---- fault injection on one memory word (inject_fault_impl, foldedmv-offload.h:146-163):
+ * target 0 = weight word (layer, mem = PE, ind), 1 = threshold (layer, mem, ind, thresh); flips
+ * word_size adjacent bits at bit_pos aligned down to word_size.  Returns the matrix row changed,
+ * or -1.  The fault stays until the oracle is destroyed, like the reference's memories. */
+int bnn_oracle_apply_fault(bnn_oracle *o, int target, int layer, int mem, int ind, int thresh, int bit_pos,
+                           int word_size);
+
 /* ---- unpacked parameters, for tests that cross-check the GPU repacker ---- */
 /* weight of (layer, row n, column j) in value domain; threshold i of row n. */
 int bnn_oracle_weight(const bnn_oracle *o, int layer, int n, int j);

@@ -56,6 +56,7 @@ def lib():
     for f in ("weight", "threshold"):
         getattr(L, "bnn_oracle_" + f).argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.bnn_oracle_layer_mw.argtypes = [vp, C.c_int]
+    L.bnn_oracle_apply_fault.argtypes = [vp] + [C.c_int] * 7
     L.bnn_oracle_layer_mh.argtypes = [vp, C.c_int]
     _lib = L
     return L
@@ -146,6 +147,10 @@ class Oracle:
                 s[i].ctypes.data_as(C.POINTER(C.c_int16)), ncls) for i in range(len(s))], np.int32)
         w = self.words_fast(imgs, nthreads)
         return np.array([L.bnn_oracle_decode_lfc_batched(int(x), ncls) for x in w], np.int32)
+
+    def apply_fault(self, rec):
+        """rec = (image, target, layer, mem, ind, thresh, bit, word_size); returns the row changed"""
+        return self.L.bnn_oracle_apply_fault(self.h, *[int(x) for x in rec[1:8]])
 
     def weights(self, layer):
         mh, mw = self.L.bnn_oracle_layer_mh(self.h, layer), self.L.bnn_oracle_layer_mw(self.h, layer)
