@@ -61,7 +61,9 @@ def issue_floor_cycles(network):
     kind, prec = network[:3], network[3:]
     cyc = WORD_MACS[kind] * PAIRS_PER_WORD[prec] * PAIR_CYC
     if kind == "cnv":
-        cyc += 900 * 64 * 8 * SLOT_CYC              # layer 0: 7 v_dot4c + 1 v_alignbit per pixel and neuron
+        # layer 0 runs on the matrix pipe (v_mfma_i32_32x32x32_i8); what stays on the integer pipe is the
+        # tap gather + quantise (~105 instructions per pixel-lane) and one v_alignbit per neuron (64) + merges
+        cyc += 900 * 170 * SLOT_CYC
     return cyc / 64.0                                # 64 lanes per wave instruction
 
 
@@ -188,7 +190,7 @@ def main():
            else "images/sec (whole node) %s batch" % a.network,
            "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "u1 (1-bit XNOR-popcount, int8 first layer)", "data": "synthetic",
+           "vs_baseline": None, "dtype": "u1 (1-bit XNOR-popcount; int8 first layer on v_mfma_i32_i8)", "data": "synthetic",
            "config": {"workload": "%s, %d synthetic %s images per GPU per step, inputs resident in HBM, params %s/%s"
                       % (a.network, a.batch, "32x32x3 uint8" if is_cnv else "28x28 uint8", dataset, a.network),
                       "images_per_gpu_per_step": a.batch, "parallelism": "dp%d (batch shards, no data-path collective)" % world},

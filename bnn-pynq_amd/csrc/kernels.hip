@@ -162,15 +162,14 @@ __device__ __forceinline__ uint32_t shift_in_sign(uint32_t bits, int v) {
   return __builtin_amdgcn_alignbit(bits, (uint32_t)v, 31);
 }
 
-template <bool OUT2>
-__global__ __launch_bounds__(kBlock) void k_conv0(const uint8_t *__restrict__ imgs, uint32_t *__restrict__ out,
-                                                   const uint32_t *__restrict__ rows, int n_items, int groups, int gpb) {
-  const BlockMap bm = map_block(groups / gpb, n_items);
-  if (!bm.valid) return;
-  const int item = bm.item;
+// The 27 int8 taps of output pixel `item` (3 channels x 3 rows x 3 columns), quantised, compacted
+// into 7 dwords: tap 3*(c*3+ky) + kx at byte tau%4 of dword tau/4; byte 27 is a don't-care byte.
+__device__ __forceinline__ void gather_taps(const uint8_t *__restrict__ imgs, int item, uint32_t (&a)[7]) {
   const int img = item / 900, p = item - img * 900;
   const int oy = p / 30, ox = p - oy * 30;
   const uint32_t *__restrict__ im32 = reinterpret_cast<const uint32_t *>(imgs + (size_t)img * 3072);
+  const uint32_t *__restrict__ row0 = im32 + oy * 8 + (ox >> 2);
+  const int last = 767 - (oy * 8 + (ox >> 2));  // the clamp below only ever feeds the don't-care byte
   const int sh = ox & 3;
   // g[c*3+r] = bytes {x, x+1, x+2, don't-care} of channel c, row oy+r
   uint32_t g[9];
@@ -178,13 +177,11 @@ __global__ __launch_bounds__(kBlock) void k_conv0(const uint8_t *__restrict__ im
   for (int c = 0; c < 3; c++)
 #pragma unroll
     for (int r = 0; r < 3; r++) {
-      const int idx = c * 256 + (oy + r) * 8 + (ox >> 2);
-      const uint32_t d0 = im32[idx];
-      const uint32_t d1 = im32[idx + 1 < 768 ? idx + 1 : 767];  // only ever feeds the don't-care byte when clamped
+      const int off = c * 256 + r * 8;
+      const uint32_t d0 = row0[off];
+      const uint32_t d1 = row0[off + 1 <= last ? off + 1 : last];
       g[c * 3 + r] = __builtin_amdgcn_alignbyte(d1, d0, sh);
     }
-  // compact the 27 taps into 7 dwords (tap 3*grp + kx at byte (3*grp+kx)%4 of dword (3*grp+kx)/4), then quantise
-  uint32_t a[7];
 #pragma unroll
   for (int h = 0; h < 2; h++) {
     a[3 * h + 0] = __builtin_amdgcn_perm(g[4 * h + 1], g[4 * h + 0], 0x04020100u);
@@ -194,6 +191,16 @@ __global__ __launch_bounds__(kBlock) void k_conv0(const uint8_t *__restrict__ im
   a[6] = g[8];  // taps 24..26 + one don't-care byte (its weight byte is 0)
 #pragma unroll
   for (int j = 0; j < 7; j++) a[j] = quantise4(a[j]);
+}
+
+template <bool OUT2>
+__global__ __launch_bounds__(kBlock) void k_conv0(const uint8_t *__restrict__ imgs, uint32_t *__restrict__ out,
+                                                   const uint32_t *__restrict__ rows, int n_items, int groups, int gpb) {
+  const BlockMap bm = map_block(groups / gpb, n_items);
+  if (!bm.valid) return;
+  const int item = bm.item;
+  uint32_t a[7];
+  gather_taps(imgs, item, a);
   // neuron groups handled by this block: gpb = all of them for large batches (one lane then
   // writes whole output words), 1 for small ones (more blocks in flight)
   for (int cg = bm.cg * gpb, cg_end = cg + gpb; cg < cg_end; cg++) {
@@ -229,6 +236,103 @@ __global__ __launch_bounds__(kBlock) void k_conv0(const uint8_t *__restrict__ im
     if constexpr (!OUT2) b0 = ~b0;  // collected !fire
     else b1 = ~b1;
     store_bits<OUT2>(out, (size_t)item, 2, cg, b0, b1);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Stage 0 on the matrix pipe.  Layer 0 is the one layer of these networks that is NOT bitwise: an
+// int8 x {-1,0,+1} contraction over 27 taps -- a small dense GEMM [64 neurons x 32] x [32 x pixels].
+// On the integer pipe it costs 8 issue slots per pixel and neuron (k_conv0, 18 % of the whole
+// cnvW1A1 run); as v_mfma_i32_32x32x32_i8 it runs on the otherwise idle matrix cores, and
+// concurrently with the popcount stages' integer work of other waves.
+//   D[neuron][pixel] = A[neuron][k] * B[k][pixel]      one wave = 64 pixels x 64 neurons = 4 MFMAs
+//   A: rows of the blob's layer-0 MFMA table {27 taps, a0, a1, 0, 0, 0},  a0 + 64*a1 = -t0 - 1
+//   B: the pixel's 27 int8 taps, then the constants 1 and 64   =>   D = dot - t0 - 1, sign bit = !fire
+// Lane l = (r = l & 31, h = l >> 5) supplies k = 16h .. 16h+15 of pixel r (B) / of neuron r (A); the
+// same (h, byte) -> k assignment on both operands is all the product needs.  The result has its
+// pixel on the lane and 16 neurons 8g + 4h + q (reg 4g + q) in registers: their sign bits are shifted
+// into nibbles, the partner half (l ^ 32) contributes the other nibbles (v_permlane32_swap), and
+// every lane ends up with the 32-neuron dword of its pixel, already in the activation layout.
+// ---------------------------------------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// sign bits of the 16 accumulators of one lane -> bits 8g + 4h + q of a dword (other bits 0)
+__device__ __forceinline__ uint32_t sign_nibbles(const int (&v)[16], int h) {
+  uint32_t x = 0;
+#pragma unroll
+  for (int g = 3; g >= 0; g--) {
+#pragma unroll
+    for (int q = 3; q >= 0; q--) x = shift_in_sign(x, v[4 * g + q]);
+    if (g) x <<= 4;
+  }
+  return x << (4 * h);
+}
+// OR with the partner lane l ^ 32
+__device__ __forceinline__ uint32_t or_halves(uint32_t x) {
+  const auto sw = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  return sw[0] | sw[1];
+}
+
+template <bool OUT2>
+__global__ __launch_bounds__(kBlock) void k_conv0_mfma(const uint8_t *__restrict__ imgs, uint32_t *__restrict__ out,
+                                                        const uint8_t *__restrict__ l0tab, int n_items) {
+  const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  const int pix = blockIdx.x * kBlock + threadIdx.x;   // lane = output pixel, like k_conv0
+  if (pix - lane >= n_items) return;                   // whole wave out of range (wave-uniform)
+  uint32_t t[7];
+  gather_taps(imgs, pix < n_items ? pix : n_items - 1, t);  // ragged tail: duplicate, store guarded
+  // K slots 27 and 28 carry the constants 1 and 64 (threshold folded into the product), 29..31 zero
+  uint32_t lo[4] = {t[0], t[1], t[2], t[3]};
+  uint32_t hi[4] = {t[4], t[5], (t[6] & 0x00FFFFFFu) | 0x01000000u, 0x00000040u};
+  // B operands of the two pixel tiles: lane (r, h) must hold k = 16h .. 16h+15 of pixel r.  Swapping
+  // the upper half of `lo` with the lower half of `hi` does exactly that for pixels 0..31 (left in lo)
+  // and for pixels 32..63 (left in hi): 4 v_permlane32_swap, no LDS.
+  v4i bp[2];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(lo[k], hi[k], false, false);
+    bp[0][k] = (int)sw[0];
+    bp[1][k] = (int)sw[1];
+  }
+  const v4i *__restrict__ atab = reinterpret_cast<const v4i *>(l0tab);
+  const int32_t *__restrict__ dtab = reinterpret_cast<const int32_t *>(l0tab + 64 * 32);
+  uint32_t w0[2] = {0, 0}, w1[2] = {0, 0};  // this lane's pixel: [neuron tile], plane 0 / plane 1
+#pragma unroll
+  for (int ct = 0; ct < 2; ct++) {
+    const v4i a = atab[(32 * ct + r) * 2 + h];
+#pragma unroll
+    for (int pt = 0; pt < 2; pt++) {
+      v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bp[pt], acc, 0, 0, 0);
+      int v[16], u[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) v[i] = acc[i];
+      uint32_t y0, y1 = 0;
+      if constexpr (!OUT2) {
+        y0 = ~or_halves(sign_nibbles(v, h));  // collected !fire
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          const int d = v[i] + dtab[32 * ct + (i & 3) + 8 * (i >> 2) + 4 * h];  // dot - t1 - 1
+          u[i] = v[i] ^ d;                                                     // f0 != f1
+          v[i] = v[i] & d;                                                     // !f0 & !f1: sign plane
+        }
+        y0 = or_halves(sign_nibbles(v, h));
+        y1 = ~or_halves(sign_nibbles(u, h));
+      }
+      // both halves now hold the words of pixel r of tile pt; a lane keeps those of its own pixel
+      const uint32_t mine = (pt == h) ? 0xFFFFFFFFu : 0u;
+      w0[ct] |= y0 & mine;
+      w1[ct] |= y1 & mine;
+    }
+  }
+  if (pix < n_items) {
+    if constexpr (!OUT2) {
+      *reinterpret_cast<uint2 *>(out + (size_t)pix * 2) = make_uint2(w0[0], w0[1]);
+    } else {  // [pixel][C/64 = 1][plane][half]
+      *reinterpret_cast<uint4 *>(out + (size_t)pix * 4) = make_uint4(w0[0], w0[1], w1[0], w1[1]);
+    }
   }
 }
 
@@ -715,7 +819,12 @@ void run_cnv_t(const CnvLaunch &a) {
   const uint64_t *A64 = reinterpret_cast<const uint64_t *>(a.buf0), *B64 = reinterpret_cast<const uint64_t *>(a.buf1);
   hipStream_t s = a.stream;
   BNN_MARK(a.events, 0, s);
-  BNN_LAUNCH((k_conv0<OUT2>), grid_for(n * 900, 2 / gpb_for(n * 900, 2)), s, a.images, A, a.rows[0], (int)(n * 900), 2, gpb_for(n * 900, 2));
+  if (a.l0_mfma) {
+    const dim3 g0((unsigned)((n * 900 + kBlock - 1) / kBlock));  // lane = pixel
+    BNN_LAUNCH((k_conv0_mfma<OUT2>), g0, s, a.images, A, a.l0_mfma, (int)(n * 900));
+  } else {
+    BNN_LAUNCH((k_conv0<OUT2>), grid_for(n * 900, 2 / gpb_for(n * 900, 2)), s, a.images, A, a.rows[0], (int)(n * 900), 2, gpb_for(n * 900, 2));
+  }
   BNN_MARK(a.events, 1, s);
   if constexpr (ARITH == AR_XNOR && !OUT2) {
     BNN_LAUNCH((k_quad_x<1, 30, true>), grid_for(n * 196, 2 / gpb_for(n * 196, 2)), s, A64, B, a.rows[1], (int)(n * 196), 2, gpb_for(n * 196, 2));

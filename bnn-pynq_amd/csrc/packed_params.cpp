@@ -106,7 +106,33 @@ void layout_header(const NetSpec &net, PackedHeader &h) {
     off += h.layer[l].row_dwords * 4 * h.layer[l].rows;
     off = (off + 255u) & ~255u;
   }
+  if (net.is_cnv) {
+    h.l0_mfma_offset = off;
+    off = (off + kL0MfmaBytes + 255u) & ~255u;
+  }
   h.total_bytes = off + 256;  // tail slack: wide scalar loads may run past the last row
+}
+
+// layer 0 of the CNV nets as an MFMA operand (packed_params.h)
+void fill_l0_mfma(const NetSpec &net, const RawParams &raw, uint8_t *dst) {
+  const LayerSpec &L = net.L[0];
+  const LayerView F{&L, &raw.w[0], &raw.t[0]};
+  int8_t *a = reinterpret_cast<int8_t *>(dst);
+  int32_t *dt = reinterpret_cast<int32_t *>(dst + 64 * 32);
+  for (int n = 0; n < 64; n++) {
+    for (int k = 0; k < 32; k++) a[n * 32 + k] = 0;
+    for (int c = 0; c < 3; c++)
+      for (int ky = 0; ky < 3; ky++)
+        for (int kx = 0; kx < 3; kx++) a[n * 32 + 3 * (c * 3 + ky) + kx] = (int8_t)F.weight(n, (ky * 3 + kx) * 3 + c);
+    int32_t T0 = F.threshold(n, 0), T1 = (L.nthr > 1) ? F.threshold(n, 1) : T0;
+    int32_t t0 = floor_div2(T0), t1 = floor_div2(T1);
+    const int32_t t0c = t0 > 3456 ? 3456 : (t0 < -3457 ? -3457 : t0);  // |dot| <= 27*128: same decisions
+    const int32_t v = -t0c - 1;
+    const int32_t a1 = (v + 32 + 64 * 128) / 64 - 128;  // floor((v + 32) / 64)
+    a[n * 32 + 27] = (int8_t)(v - 64 * a1);
+    a[n * 32 + 28] = (int8_t)a1;
+    dt[n] = t0c - t1;
+  }
 }
 
 }  // namespace
@@ -150,6 +176,7 @@ void pack_blob(const NetSpec &net, const RawParams &raw, std::vector<uint8_t> &b
     uint32_t *rows = reinterpret_cast<uint32_t *>(blob.data() + h.layer[l].offset);
     for (int n = 0; n < L.mh(); n++) fill_row(L, F, n, rows + (size_t)n * rd, rd);
   }
+  if (h.l0_mfma_offset) fill_l0_mfma(net, raw, blob.data() + h.l0_mfma_offset);
 }
 
 void repack_row(const NetSpec &net, const RawParams &raw, int l, int n, std::vector<uint8_t> &blob, size_t *offset,
@@ -163,6 +190,11 @@ void repack_row(const NetSpec &net, const RawParams &raw, int l, int n, std::vec
   fill_row(L, F, n, reinterpret_cast<uint32_t *>(blob.data() + off), rd);
   *offset = off;
   *bytes = (size_t)rd * 4;
+  if (l == 0 && h.l0_mfma_offset) {  // keep the matrix-pipe copy of layer 0 in step: report one span covering both
+    fill_l0_mfma(net, raw, blob.data() + h.l0_mfma_offset);
+    *offset = h.layer[0].offset;
+    *bytes = (size_t)h.l0_mfma_offset + kL0MfmaBytes - h.layer[0].offset;
+  }
 }
 
 std::string pack_params_from_dir(const NetSpec &net, const std::string &dir, std::vector<uint8_t> &blob) {

@@ -55,9 +55,17 @@ struct PackedLayer {
 
 struct PackedHeader {
   uint32_t magic0, magic1, version, net_id;
-  uint32_t nlayers, total_bytes, reserved0, reserved1;
+  uint32_t nlayers, total_bytes;
+  uint32_t l0_mfma_offset;  // CNV nets: layer 0 once more, as the A operand of v_mfma_i32_32x32x32_i8 (0: none)
+  uint32_t reserved1;
   PackedLayer layer[9];
 };
+
+// Layer 0 for the matrix pipe: 64 rows of 32 int8 = {27 taps in the order of the AR_INT8 rows, a0, a1, 0, 0, 0}
+// with  a0 + 64*a1 = -t0 - 1  (t0 clamped to the reachable range of the dot product, +-3456), followed by
+// 64 int32  t0 - t1  (second threshold of the 2-bit nets).  The activation operand carries the
+// constants 1 and 64 in K slots 27 and 28, so the MFMA result is  dot - t0 - 1 : its sign bit is !fire.
+constexpr uint32_t kL0MfmaBytes = 64 * 32 + 64 * 4;
 static_assert(sizeof(PackedHeader) == 32 + 9 * 16, "blob header layout");
 
 uint32_t row_dwords_for(const LayerSpec &L);

@@ -49,6 +49,7 @@ struct Runtime {
   uint64_t fault_seed = 0;  // 0: std::random_device, like the reference
   std::vector<Fault> last_faults;
   const uint32_t *rows[9] = {};
+  const uint8_t *l0_mfma = nullptr;  // layer 0 as an MFMA operand (CNV nets), unless BNN_MI355X_L0=valu
   // workspace
   int cap = 0;
   void *buf0 = nullptr, *buf1 = nullptr;
@@ -104,6 +105,9 @@ int upload_blob() {
   const PackedHeader *h = reinterpret_cast<const PackedHeader *>(r.blob.data());
   for (int l = 0; l < r.spec.nlayers; l++)
     r.rows[l] = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(r.d_blob) + h->layer[l].offset);
+  const char *l0 = std::getenv("BNN_MI355X_L0");
+  const bool valu = l0 && std::strcmp(l0, "valu") == 0;
+  r.l0_mfma = (h->l0_mfma_offset && !valu) ? static_cast<const uint8_t *>(r.d_blob) + h->l0_mfma_offset : nullptr;
   return 0;
 }
 
@@ -157,6 +161,7 @@ int enqueue(const uint8_t *d_imgs, int n, int ncls, int32_t *d_classes, int16_t 
     CnvLaunch a{};
     a.images = d_imgs; a.n = n; a.buf0 = r.buf0; a.buf1 = r.buf1;
     for (int l = 0; l < 9; l++) a.rows[l] = r.rows[l];
+    a.l0_mfma = r.l0_mfma;
     a.scores = d_scores; a.classes = d_classes; a.number_class = ncls; a.stream = s; a.events = evs;
     e = run_cnv(r.spec.id, a);
   } else {
