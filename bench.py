@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--dataset", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target length of the CPU baseline leg")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="multi-rank dry run on ONE GPU: gloo instead of RCCL, every rank computes on cuda:0 "
+                         "(exercises launch/broadcast/shard/timing code where only one GPU is available)")
     return ap.parse_args()
 
 
@@ -96,11 +99,16 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product has no CPU path")
+    if a.rehearse_gloo:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if a.rehearse_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
     L = gl.load(a.network)
     assert L.bnn_mi355x_set_device(local_rank) == 0
@@ -115,7 +123,7 @@ def main():
     else:
         # rank 0 reads + repacks the files; the ~210 KB blob goes to the other GPUs over RCCL/xGMI:
         # the one collective of the whole job
-        mg.distribute_params(L, pdir, device=dev)
+        mg.distribute_params(L, pdir, device=None if a.rehearse_gloo else dev)
 
     # ---- synthetic batch, resident in HBM before the timed region starts
     g = torch.Generator(device=dev)
@@ -150,7 +158,7 @@ def main():
     nst = L.bnn_mi355x_profile_read(stage_ms, 16, C.byref(nchunks))
     L.bnn_mi355x_profile(0)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if a.rehearse_gloo else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
