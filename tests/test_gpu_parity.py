@@ -233,3 +233,53 @@ def test_lfc_device_decode():
     o = oracle("lfcW1A1", "mnist")
     assert (words.cpu().numpy().view(np.uint64) == o.words_fast(imgs)).all()
     assert cls.cpu().numpy().tolist() == o.classes_batched(imgs, 10).tolist()
+
+
+def test_abi_edge_behaviour(tmp_path):
+    """NULL out-params, deinit() between calls, bad inputs: errors are reported, never thrown across the ABI"""
+    net = gpu_net("cnvW1A1", "cifar10")
+    L = net.L
+    deer = os.path.join(ol.GOLDEN, "deer.cifar").encode()
+    p = L.inference_multiple(deer, 10, None, None, 0)            # both out-params NULL (bnn.py passes pointers, C callers may not)
+    assert p and p[0] == 4
+    L.free_results(p)
+    L.deinit()                                                   # frees the I/O workspace only (FoldedMVDeinit): weights stay
+    assert L.inference(deer, None, 10, None) == 4
+    L.deinit()
+    L.deinit()                                                   # idempotent
+    n = C.c_int(-1)
+    assert not L.inference_multiple(b"/nonexistent/file.bin", 10, C.byref(n), None, 0)
+    assert b"Could not open file" in L.bnn_mi355x_last_error()
+    assert L.inference(b"/nonexistent/file.bin", None, 10, None) == -1
+    assert not L.bnn_mi355x_inference_buffer(None, 5, 10, None, 0)
+    imgs = rand_images("cnvW1A1", 4, 2)
+    assert not L.bnn_mi355x_inference_buffer(imgs.ctypes.data, 4, 0, None, 0)      # number_class out of 1..64
+    assert not L.bnn_mi355x_inference_buffer(imgs.ctypes.data, 4, 65, None, 0)
+    empty = tmp_path / "empty.bin"
+    empty.write_bytes(b"")
+    p = L.inference_multiple(str(empty).encode(), 10, C.byref(n), None, 0)          # zero records: an empty result, not an error
+    assert p and n.value == 0
+    L.free_results(p)
+    assert L.inference(str(empty).encode(), None, 10, None) == -1
+    short = tmp_path / "short.bin"
+    short.write_bytes(open(os.path.join(ol.GOLDEN, "deer.cifar"), "rb").read() + b"\x01" * 100)   # trailing partial record ignored
+    p = L.inference_multiple(str(short).encode(), 10, C.byref(n), None, 0)
+    assert n.value == 1 and p[0] == 4
+    L.free_results(p)
+    assert net.raw(imgs).shape == (4, 64)                        # still healthy afterwards
+
+
+def test_layer0_integer_pipe_kernel_agrees():
+    """BNN_MI355X_L0=valu selects k_conv0 (v_dot4c) instead of the MFMA first layer: same bits"""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); import torch, gpu_lib as gl, oracle_lib as ol\n"
+        "for net in ('cnvW1A1', 'cnvW2A2'):\n"
+        "    imgs = np.random.default_rng(5).integers(0, 256, (700, 3072), dtype=np.uint8)\n"
+        "    got = gl.Net(net, 'cifar10').raw(imgs)\n"
+        "    assert (got == ol.Oracle(net, ol.param_dir('cifar10', net)).scores_fast(imgs)).all(), net\n"
+        "print('valu-l0-ok')\n" % os.path.join(gl.ROOT, "tests"))
+    env = dict(os.environ, BNN_MI355X_L0="valu")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert "valu-l0-ok" in out.stdout, out.stdout + out.stderr
