@@ -37,6 +37,7 @@ namespace bnn {
 namespace {
 
 constexpr int kMaxChunk = 131072;  // images per pass through the stages
+constexpr int kHostChunk = 32768;  // host-buffer path: H2D of chunk i+1 overlaps the stages of chunk i
 
 struct Runtime {
   const NetSpec &spec = net_spec(BNN_NETWORK);
@@ -53,12 +54,16 @@ struct Runtime {
   // workspace
   int cap = 0;
   void *buf0 = nullptr, *buf1 = nullptr;
-  uint8_t *d_images = nullptr;
+  // host-buffer path: two image staging buffers in HBM (ping-pong) + results for the whole call
+  int stage_cap = 0;
+  uint8_t *d_images[2] = {nullptr, nullptr};
+  size_t res_cap = 0;
   int16_t *d_scores = nullptr;
   int32_t *d_classes = nullptr;
   uint64_t *d_words = nullptr;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t stream = nullptr, copy_stream = nullptr;
+  hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
+  std::vector<hipEvent_t> time_events;
   // optional per-stage profiling (bnn_mi355x_profile): one event set per enqueued chunk
   bool profiling = false;
   std::vector<std::vector<hipEvent_t>> prof_sets;
@@ -90,8 +95,11 @@ int bind_device() {
   if (r.device >= 0) HIP_OK(hipSetDevice(r.device));
   if (!r.stream) {
     HIP_OK(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
-    HIP_OK(hipEventCreate(&r.ev0));
-    HIP_OK(hipEventCreate(&r.ev1));
+    HIP_OK(hipStreamCreateWithFlags(&r.copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+      HIP_OK(hipEventCreateWithFlags(&r.copied[i], hipEventDisableTiming));
+      HIP_OK(hipEventCreateWithFlags(&r.consumed[i], hipEventDisableTiming));
+    }
   }
   return 0;
 }
@@ -113,32 +121,62 @@ int upload_blob() {
 
 void free_workspace() {
   Runtime &r = rt();
-  if (r.cap == 0) return;
+  if (r.cap == 0 && r.stage_cap == 0 && r.res_cap == 0) return;
   if (r.device >= 0) (void)hipSetDevice(r.device);
-  (void)hipFree(r.buf0); (void)hipFree(r.buf1); (void)hipFree(r.d_images);
+  (void)hipDeviceSynchronize();
+  (void)hipFree(r.buf0); (void)hipFree(r.buf1); (void)hipFree(r.d_images[0]); (void)hipFree(r.d_images[1]);
   (void)hipFree(r.d_scores); (void)hipFree(r.d_classes); (void)hipFree(r.d_words);
-  r.buf0 = r.buf1 = nullptr; r.d_images = nullptr; r.d_scores = nullptr; r.d_classes = nullptr; r.d_words = nullptr;
-  r.cap = 0;
+  r.buf0 = r.buf1 = nullptr; r.d_images[0] = r.d_images[1] = nullptr;
+  r.d_scores = nullptr; r.d_classes = nullptr; r.d_words = nullptr;
+  r.cap = r.stage_cap = 0;
+  r.res_cap = 0;
 }
 
-// workspace for `n` images per pass (at most kMaxChunk)
+// activation workspace for `n` images per pass (at most kMaxChunk)
 int reserve(int n) {
   Runtime &r = rt();
   if (n > kMaxChunk) n = kMaxChunk;
   if (n <= r.cap) return 0;
   if (bind_device()) return -1;
-  free_workspace();
+  HIP_OK(hipDeviceSynchronize());
+  (void)hipFree(r.buf0); (void)hipFree(r.buf1);
+  r.buf0 = r.buf1 = nullptr;
+  r.cap = 0;
   size_t b0, b1;
   if (r.spec.is_cnv) cnv_workspace_bytes(r.spec.abits, &b0, &b1);
   else lfc_workspace_bytes(r.spec.abits, &b0, &b1);
-  const size_t N = (size_t)n;
-  HIP_OK(hipMalloc(&r.buf0, N * b0 + 256));
-  HIP_OK(hipMalloc(&r.buf1, N * b1 + 256));
-  HIP_OK(hipMalloc(reinterpret_cast<void **>(&r.d_images), N * r.spec.image_bytes() + 256));
-  HIP_OK(hipMalloc(reinterpret_cast<void **>(&r.d_scores), N * 64 * sizeof(int16_t)));
-  HIP_OK(hipMalloc(reinterpret_cast<void **>(&r.d_classes), N * sizeof(int32_t)));
-  HIP_OK(hipMalloc(reinterpret_cast<void **>(&r.d_words), N * sizeof(uint64_t)));
+  HIP_OK(hipMalloc(&r.buf0, (size_t)n * b0 + 256));
+  HIP_OK(hipMalloc(&r.buf1, (size_t)n * b1 + 256));
   r.cap = n;
+  return 0;
+}
+
+// host-buffer path: staging for `chunk` images x 2 and result buffers for `n_total` images
+int reserve_host(int chunk, size_t n_total) {
+  Runtime &r = rt();
+  if (bind_device()) return -1;
+  if (chunk > r.stage_cap) {
+    HIP_OK(hipDeviceSynchronize());
+    for (int i = 0; i < 2; i++) {
+      (void)hipFree(r.d_images[i]);
+      r.d_images[i] = nullptr;
+    }
+    r.stage_cap = 0;
+    for (int i = 0; i < 2; i++)
+      HIP_OK(hipMalloc(reinterpret_cast<void **>(&r.d_images[i]), (size_t)chunk * r.spec.image_bytes() + 256));
+    r.stage_cap = chunk;
+  }
+  if (n_total > r.res_cap) {
+    HIP_OK(hipDeviceSynchronize());
+    (void)hipFree(r.d_scores); (void)hipFree(r.d_classes); (void)hipFree(r.d_words);
+    r.d_scores = nullptr; r.d_classes = nullptr; r.d_words = nullptr;
+    r.res_cap = 0;
+    const size_t N = n_total < 1024 ? 1024 : n_total;
+    if (r.spec.is_cnv) HIP_OK(hipMalloc(reinterpret_cast<void **>(&r.d_scores), N * 64 * sizeof(int16_t)));
+    HIP_OK(hipMalloc(reinterpret_cast<void **>(&r.d_classes), N * sizeof(int32_t)));
+    HIP_OK(hipMalloc(reinterpret_cast<void **>(&r.d_words), N * sizeof(uint64_t)));
+    r.res_cap = N;
+  }
   return 0;
 }
 
@@ -168,7 +206,7 @@ int enqueue(const uint8_t *d_imgs, int n, int ncls, int32_t *d_classes, int16_t 
     LfcLaunch a{};
     a.images = d_imgs; a.n = n; a.buf0 = r.buf0; a.buf1 = r.buf1;
     for (int l = 0; l < 4; l++) a.rows[l] = r.rows[l];
-    a.words = d_words ? d_words : r.d_words;
+    a.words = d_words;
     a.classes = d_classes; a.number_class = ncls; a.stream = s; a.events = evs;
     e = run_lfc(r.spec.id, a);
   }
@@ -188,28 +226,45 @@ int infer_host(const uint8_t *imgs, int n, int ncls, int32_t *classes, int16_t *
   Runtime &r = rt();
   if (!ready()) return -1;
   if (ncls < 1 || ncls > 64) return fail("number_class must be in 1..64");
-  double total_ms = 0.0;
+  if (usec) *usec = 0.f;
+  if (n <= 0) return 0;
   const size_t isz = (size_t)r.spec.image_bytes();
-  for (int base = 0; base < n; base += kMaxChunk) {
-    const int m = (n - base < kMaxChunk) ? n - base : kMaxChunk;
-    if (reserve(m)) return -1;
-    HIP_OK(hipMemcpyAsync(r.d_images, imgs + (size_t)base * isz, (size_t)m * isz, hipMemcpyHostToDevice, r.stream));
-    HIP_OK(hipEventRecord(r.ev0, r.stream));
-    if (enqueue(r.d_images, m, ncls, classes ? r.d_classes : nullptr, (scores && r.spec.is_cnv) ? r.d_scores : nullptr,
-                r.d_words, r.stream))
+  const int chunk = n < kHostChunk ? n : kHostChunk;
+  const int nchunks = (n + chunk - 1) / chunk;
+  if (reserve(chunk) || reserve_host(chunk, (size_t)n)) return -1;
+  while ((int)r.time_events.size() < 2 * nchunks) {
+    hipEvent_t e;
+    HIP_OK(hipEventCreate(&e));
+    r.time_events.push_back(e);
+  }
+  const bool want_scores = scores && r.spec.is_cnv;
+  // Two staging buffers: the copy engine fills one while the stages consume the other.  Results of
+  // every chunk stay in HBM and come back in one transfer at the end (a D2H into pageable memory
+  // would otherwise make the host wait for each chunk's kernels before it can queue the next copy).
+  for (int c = 0; c < nchunks; c++) {
+    const int base = c * chunk, m = (n - base < chunk) ? n - base : chunk, slot = c & 1;
+    if (c >= 2) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));
+    HIP_OK(hipMemcpyAsync(r.d_images[slot], imgs + (size_t)base * isz, (size_t)m * isz, hipMemcpyHostToDevice, r.copy_stream));
+    HIP_OK(hipEventRecord(r.copied[slot], r.copy_stream));
+    HIP_OK(hipStreamWaitEvent(r.stream, r.copied[slot], 0));
+    HIP_OK(hipEventRecord(r.time_events[2 * c], r.stream));
+    if (enqueue(r.d_images[slot], m, ncls, classes ? r.d_classes + base : nullptr, want_scores ? r.d_scores + (size_t)base * 64 : nullptr,
+                r.d_words + base, r.stream))
       return -1;
-    HIP_OK(hipEventRecord(r.ev1, r.stream));
-    if (classes) HIP_OK(hipMemcpyAsync(classes + base, r.d_classes, (size_t)m * 4, hipMemcpyDeviceToHost, r.stream));
-    if (scores && r.spec.is_cnv)
-      HIP_OK(hipMemcpyAsync(scores + (size_t)base * 64, r.d_scores, (size_t)m * 128, hipMemcpyDeviceToHost, r.stream));
-    if (words && !r.spec.is_cnv)
-      HIP_OK(hipMemcpyAsync(words + base, r.d_words, (size_t)m * 8, hipMemcpyDeviceToHost, r.stream));
-    HIP_OK(hipStreamSynchronize(r.stream));
+    HIP_OK(hipEventRecord(r.time_events[2 * c + 1], r.stream));
+    HIP_OK(hipEventRecord(r.consumed[slot], r.stream));
+  }
+  if (classes) HIP_OK(hipMemcpyAsync(classes, r.d_classes, (size_t)n * 4, hipMemcpyDeviceToHost, r.stream));
+  if (want_scores) HIP_OK(hipMemcpyAsync(scores, r.d_scores, (size_t)n * 128, hipMemcpyDeviceToHost, r.stream));
+  if (words && !r.spec.is_cnv) HIP_OK(hipMemcpyAsync(words, r.d_words, (size_t)n * 8, hipMemcpyDeviceToHost, r.stream));
+  HIP_OK(hipStreamSynchronize(r.stream));
+  double total_ms = 0.0;
+  for (int c = 0; c < nchunks; c++) {
     float ms = 0.f;
-    HIP_OK(hipEventElapsedTime(&ms, r.ev0, r.ev1));
+    HIP_OK(hipEventElapsedTime(&ms, r.time_events[2 * c], r.time_events[2 * c + 1]));
     total_ms += ms;
   }
-  if (usec) *usec = n > 0 ? (float)(total_ms * 1000.0 / n) : 0.f;
+  if (usec) *usec = (float)(total_ms * 1000.0 / n);
   return 0;
 }
 
@@ -427,7 +482,7 @@ const char *bnn_mi355x_last_error(void) { return rt().err.c_str(); }
 
 int bnn_mi355x_set_device(int ordinal) {
   Runtime &r = rt();
-  if (r.d_blob || r.cap) return fail("set_device must be called before load_parameters");
+  if (r.d_blob || r.cap || r.stage_cap) return fail("set_device must be called before load_parameters");
   r.device = ordinal;
   return 0;
 }
@@ -561,6 +616,10 @@ int bnn_mi355x_inference_device(const void *d_images, int n_images, int number_c
   if (number_class < 1 || number_class > 64) return fail("number_class must be in 1..64");
   hipStream_t s = static_cast<hipStream_t>(hip_stream);
   const size_t isz = (size_t)r.spec.image_bytes();
+  if (!r.spec.is_cnv && !d_words) {  // the LFC decode stage reads the raw words: give it somewhere to put them
+    if (reserve_host(1, (size_t)n_images)) return -1;
+    d_words = r.d_words;
+  }
   for (int base = 0; base < n_images; base += kMaxChunk) {
     const int m = (n_images - base < kMaxChunk) ? n_images - base : kMaxChunk;
     if (reserve(m)) return -1;
