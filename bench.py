@@ -187,12 +187,23 @@ def main():
             traffic = int((t["fetch_bytes_per_image_x2"] + t["write_bytes_per_image"]) * imgs_per_launch)
         except Exception:
             traffic = None
+    # the dominant kernel on its own: bytes that one stage must move per image (input map + output map)
+    own_bytes = {"k_conv0 (L0)": 3072 + 7200, "k_quad L1+pool": 7200 + 1568, "k_quad L2": 1568 + 2304, "k_quad L3+pool": 2304 + 400,
+                 "k_vec L0": 104 + 128, "k_vec L1": 256, "k_vec L2": 256}
+    planes = 2 if a.network.endswith("A2") else 1
+    dom_alg = own_bytes.get(names[dom])
+    dominant = {"name": names[dom], "ms_per_launch": round(per_stage[dom] * a.steps / launches, 4)}
+    if dom_alg:
+        dom_alg *= planes
+        dominant.update({"algorithmic_bytes_per_image": dom_alg,
+                         "achieved": round(dom_alg * a.batch / (per_stage[dom] * 1e-3) / 1e9, 2), "unit": "GB/s",
+                         "frac": round(dom_alg * a.batch / (per_stage[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)})
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                 "kernel": "all %d stages of one batch (dominant: %s, %.1f%% of device time)" % (
                     nst, names[dom], 100.0 * per_stage[dom] / dev_ms),
                 "algorithmic_bytes_per_image": alg, "images_per_launch": int(imgs_per_launch),
-                "device_ms_per_step": round(dev_ms, 4),
+                "device_ms_per_step": round(dev_ms, 4), "dominant_kernel": dominant,
                 "stages_ms": {names[i]: round(per_stage[i], 4) for i in range(nst)}}
     out = {"metric": "images/sec (whole node) CNV-W1A1 CIFAR-10-shape batch" if a.network == "cnvW1A1"
            else "images/sec (whole node) %s batch" % a.network,

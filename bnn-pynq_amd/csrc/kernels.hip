@@ -79,18 +79,6 @@ __device__ __forceinline__ void store_bits(uint32_t *__restrict__ out, size_t pi
   }
 }
 
-// fire0/fire1 = (T0 < acc), (T1 < acc).  1-bit: bit = fire0.
-// 2-bit: value = -1 + fire0 + fire1 -> sign = !(f0|f1), non-zero = (f0 == f1)
-template <bool OUT2>
-__device__ __forceinline__ void push_bits(uint32_t &b0, uint32_t &b1, bool f0, bool f1, uint32_t bit) {
-  if constexpr (!OUT2) {
-    b0 |= f0 ? bit : 0u;
-  } else {
-    b0 |= (!f0 && !f1) ? bit : 0u;
-    b1 |= (f0 == f1) ? bit : 0u;
-  }
-}
-
 // ---------------------------------------------------------------------------
 // one neuron x one window: the MVAU inner product on bit-packed words
 // ---------------------------------------------------------------------------
@@ -116,24 +104,12 @@ constexpr int planes_in() { return ARITH == AR_XNOR ? 1 : 2; }
 template <int ARITH>
 constexpr int wplanes() { return ARITH == AR_TT ? 2 : 1; }
 
-// turns (m, z, nz_total) into the quantity compared with the thresholds.
-// XNOR family: smaller is "more positive" -> we compare m < t, so for pooling
-// take the MIN over the quad; ternary family: acc, take the MAX.
+// (m, z, nz_total) -> the signed accumulator of the ternary forms (used by the last CNV layer)
 template <int ARITH>
 __device__ __forceinline__ int finish(int m, int z, int nzt) {
   if constexpr (ARITH == AR_XNOR) return m;
   else if constexpr (ARITH == AR_TB) return nzt - 2 * m;
   else return z - 2 * m;
-}
-template <int ARITH>
-__device__ __forceinline__ bool fires(int v, int t) {
-  if constexpr (ARITH == AR_XNOR) return v < t;
-  else return t < v;
-}
-template <int ARITH>
-__device__ __forceinline__ int pool2(int a, int b) {
-  if constexpr (ARITH == AR_XNOR) return a < b ? a : b;
-  else return a > b ? a : b;
 }
 
 // ---------------------------------------------------------------------------
