@@ -76,7 +76,7 @@ def parse():
     ap.add_argument("--network", default="cnvW1A1")
     ap.add_argument("--dataset", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target length of the CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target length of the CPU baseline leg")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="multi-rank dry run on ONE GPU: gloo instead of RCCL, every rank computes on cuda:0 "
                          "(exercises launch/broadcast/shard/timing code where only one GPU is available)")
@@ -226,7 +226,7 @@ def main():
     if world == 1 and not a.no_cpu_baseline:
         import oracle_lib as ol
         o = ol.Oracle(a.network, ol.param_dir(dataset, a.network))
-        host = imgs[: min(a.batch, 65536)].cpu().numpy()
+        host = imgs[: min(a.batch, 262144)].cpu().numpy()
         cores = host_cores()
         probe = min(256, host.shape[0])
         run = (lambda x: o.scores_fast(x, cores)) if is_cnv else (lambda x: o.words_fast(x, cores))
