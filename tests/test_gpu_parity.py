@@ -219,6 +219,34 @@ def test_device_api_and_blob_roundtrip():
     assert (net.raw(imgs[:64]) == want[:64]).all()
 
 
+def test_device_api_crosses_the_chunk_boundary():
+    """more images than one pass holds (131 072): the device entry point walks the batch in chunks;
+    results must not depend on where the boundary falls"""
+    import torch
+    net = gpu_net("cnvW1A1", "cifar10")
+    n = 131072 + 777
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    d = torch.randint(0, 256, (n, 3072), dtype=torch.uint8, device="cuda", generator=g)
+    cls = torch.zeros(n, dtype=torch.int32, device="cuda")
+    sc = torch.zeros(n, 64, dtype=torch.int16, device="cuda")
+    torch.cuda.synchronize()
+    assert net.L.bnn_mi355x_inference_device(d.data_ptr(), n, 10, cls.data_ptr(), sc.data_ptr(), None, None) == 0
+    torch.cuda.synchronize()
+    pick = np.concatenate([np.arange(131072 - 150, 131072 + 150), np.array([0, n - 1]), np.random.default_rng(3).choice(n, 100)])
+    host = d[torch.from_numpy(pick).cuda()].cpu().numpy()
+    o = oracle("cnvW1A1", "cifar10")
+    assert (sc.cpu().numpy()[pick] == o.scores_fast(host)).all()
+    assert cls.cpu().numpy()[pick].tolist() == o.classes_batched(host, 10).tolist()
+    # the tail chunk alone gives the same answers
+    tail = d[131072:].contiguous()
+    cls2 = torch.zeros(n - 131072, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    assert net.L.bnn_mi355x_inference_device(tail.data_ptr(), n - 131072, 10, cls2.data_ptr(), None, None, None) == 0
+    torch.cuda.synchronize()
+    assert (cls2 == cls[131072:]).all()
+
+
 def test_lfc_device_decode():
     import torch
     net = gpu_net("lfcW1A1", "mnist")
