@@ -41,6 +41,7 @@ typedef const uint32_t __attribute__((address_space(4))) *kptr32;
 typedef const uint64_t __attribute__((address_space(4))) *kptr64;
 
 constexpr int kBlock = 256;
+constexpr int kLfcFusedMax = 128;  // images: below this the block-per-image LFC kernel wins (tools/latency.py)
 
 // Block -> (work-item block, neuron group), XCD-aware.  The `groups` blocks that evaluate
 // different 32-neuron groups for the SAME 256 work items read the same input windows and write
@@ -756,6 +757,81 @@ __global__ __launch_bounds__(kBlock) void k_lfc_binarize(const uint8_t *__restri
   out[t] = word;
 }
 
+// ---------------------------------------------------------------------------
+// Latency form of lfcW1A1: ONE launch, one 1024-thread block per image, the whole 784 -> 1024 ->
+// 1024 -> 1024 -> 64 network.  Here the parallelism of a single image is its NEURONS: thread n of the
+// block owns neuron n of the layer (its weight row comes straight from L2 into VGPRs), the layer's
+// input vector is the same for all threads (16 words in LDS, read as broadcasts), and the 64
+// decisions of a wave are packed by the wave itself -- __ballot IS the wavefront reduction here:
+// v_cmp writes the 64-bit lane mask, which is exactly the next layer's input word.  Three
+// __syncthreads() separate the layers.  Used for small batches, where the throughput kernels
+// (one lane per IMAGE) would leave the chip empty: 1 image 44 us -> see profiles/.
+// ---------------------------------------------------------------------------
+template <int KW>
+__device__ __forceinline__ void lfc_load_row(const uint32_t *__restrict__ rows, int n, uint64_t (&w)[KW], int &t) {
+  constexpr int ROW_DW = 2 + 2 * KW;
+  const uint32_t *__restrict__ r = rows + (size_t)n * ROW_DW;
+  const uint64_t *__restrict__ p = reinterpret_cast<const uint64_t *>(r + 2);
+  t = (int)r[0];
+#pragma unroll
+  for (int k = 0; k < KW; k++) w[k] = p[k];
+}
+template <int KW>
+__device__ __forceinline__ bool lfc_fires(const uint64_t (&w)[KW], int t, const uint64_t *act) {
+  int m = 0;
+#pragma unroll
+  for (int k = 0; k < KW; k++) m += pc64(w[k] ^ act[k]);
+  return m < t;
+}
+
+__global__ __launch_bounds__(1024) void k_lfc_fused(const uint8_t *__restrict__ imgs, uint64_t *__restrict__ words,
+                                                     int32_t *__restrict__ classes, const uint32_t *__restrict__ r0,
+                                                     const uint32_t *__restrict__ r1, const uint32_t *__restrict__ r2,
+                                                     const uint32_t *__restrict__ r3, int number_class) {
+  __shared__ uint64_t act[2][16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, img = blockIdx.x;
+  // the layers are a dependent chain, their weight traffic need not be: the row of layer L+1 is
+  // requested before layer L is evaluated (two rows in flight: more would spill at 1024 threads)
+  uint64_t w0[13], w1[16], w2[16], w3[16];
+  int t0, t1, t2, t3 = 0;
+  const uint8_t px = (t < 784) ? imgs[(size_t)img * 784 + t] : 0;
+  lfc_load_row<13>(r0, t, w0, t0);
+  // binarizeAndPack: bit i = (pixel i >= 128); pixels 784..831 are padding (0)
+  {
+    const uint64_t word = __ballot(px >= 128);
+    if (lane == 0) act[0][wave] = word;  // waves 13..15 write zeros
+  }
+  lfc_load_row<16>(r1, t, w1, t1);
+  __syncthreads();
+  {
+    const uint64_t word = __ballot(lfc_fires<13>(w0, t0, act[0]));
+    if (lane == 0) act[1][wave] = word;
+  }
+  lfc_load_row<16>(r2, t, w2, t2);
+  __syncthreads();
+  {
+    const uint64_t word = __ballot(lfc_fires<16>(w1, t1, act[1]));
+    if (lane == 0) act[0][wave] = word;
+  }
+  if (wave == 0) lfc_load_row<16>(r3, lane, w3, t3);
+  __syncthreads();
+  {
+    const uint64_t word = __ballot(lfc_fires<16>(w2, t2, act[0]));
+    if (lane == 0) act[1][wave] = word;
+  }
+  __syncthreads();
+  if (wave == 0) {  // last layer: 64 neurons, one wave
+    const uint64_t word = __ballot(lfc_fires<16>(w3, t3, act[1]));
+    if (lane == 0) {
+      words[img] = word;
+      if (classes) {
+        const uint64_t w = word & (~0ull >> (64 - number_class));
+        classes[img] = w ? 63 - __builtin_clzll(w) : 0;
+      }
+    }
+  }
+}
+
 // LFC output decode, batched form (testPrebinarized_nolabel_multiple_images,
 // foldedmv-offload.cpp:202-220): mask to number_class bits, class = index of
 // the highest set bit, 0 when none.  (unsigned)log2((double)w) equals that
@@ -874,6 +950,12 @@ hipError_t run_lfc(NetId net, const LfcLaunch &a) {
   uint32_t *A = reinterpret_cast<uint32_t *>(a.buf0), *B = reinterpret_cast<uint32_t *>(a.buf1);
   uint64_t *A64 = reinterpret_cast<uint64_t *>(a.buf0), *B64 = reinterpret_cast<uint64_t *>(a.buf1);
   hipStream_t s = a.stream;
+  if (net == NET_LFCW1A1 && n <= kLfcFusedMax && !a.events) {
+    // small batch: the one-launch, block-per-image form (no per-stage events: there are no stages)
+    hipLaunchKernelGGL(k_lfc_fused, dim3((unsigned)n), dim3(1024), 0, s, a.images, a.words, a.classes, a.rows[0], a.rows[1],
+                       a.rows[2], a.rows[3], a.number_class);
+    return hipGetLastError();
+  }
   BNN_MARK(a.events, 0, s);
   BNN_LAUNCH(k_lfc_binarize, grid_for(n * 13, 1), s, a.images, A64, (int)(n * 13));
   BNN_MARK(a.events, 1, s);

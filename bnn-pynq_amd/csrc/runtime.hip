@@ -243,16 +243,20 @@ int infer_host(const uint8_t *imgs, int n, int ncls, int32_t *classes, int16_t *
   // would otherwise make the host wait for each chunk's kernels before it can queue the next copy).
   for (int c = 0; c < nchunks; c++) {
     const int base = c * chunk, m = (n - base < chunk) ? n - base : chunk, slot = c & 1;
-    if (c >= 2) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));
-    HIP_OK(hipMemcpyAsync(r.d_images[slot], imgs + (size_t)base * isz, (size_t)m * isz, hipMemcpyHostToDevice, r.copy_stream));
-    HIP_OK(hipEventRecord(r.copied[slot], r.copy_stream));
-    HIP_OK(hipStreamWaitEvent(r.stream, r.copied[slot], 0));
+    if (nchunks == 1) {  // nothing to overlap: stay on one stream (fewer driver round trips for small calls)
+      HIP_OK(hipMemcpyAsync(r.d_images[slot], imgs, (size_t)m * isz, hipMemcpyHostToDevice, r.stream));
+    } else {
+      if (c >= 2) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));
+      HIP_OK(hipMemcpyAsync(r.d_images[slot], imgs + (size_t)base * isz, (size_t)m * isz, hipMemcpyHostToDevice, r.copy_stream));
+      HIP_OK(hipEventRecord(r.copied[slot], r.copy_stream));
+      HIP_OK(hipStreamWaitEvent(r.stream, r.copied[slot], 0));
+    }
     HIP_OK(hipEventRecord(r.time_events[2 * c], r.stream));
     if (enqueue(r.d_images[slot], m, ncls, classes ? r.d_classes + base : nullptr, want_scores ? r.d_scores + (size_t)base * 64 : nullptr,
                 r.d_words + base, r.stream))
       return -1;
     HIP_OK(hipEventRecord(r.time_events[2 * c + 1], r.stream));
-    HIP_OK(hipEventRecord(r.consumed[slot], r.stream));
+    if (nchunks > 1) HIP_OK(hipEventRecord(r.consumed[slot], r.stream));
   }
   if (classes) HIP_OK(hipMemcpyAsync(classes, r.d_classes, (size_t)n * 4, hipMemcpyDeviceToHost, r.stream));
   if (want_scores) HIP_OK(hipMemcpyAsync(scores, r.d_scores, (size_t)n * 128, hipMemcpyDeviceToHost, r.stream));

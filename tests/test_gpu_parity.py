@@ -247,6 +247,23 @@ def test_device_api_crosses_the_chunk_boundary():
     assert (cls2 == cls[131072:]).all()
 
 
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 128, 129])
+def test_lfc_small_batches_take_the_fused_kernel(n):
+    """<= 128 images: lfcW1A1 runs as one launch, one block per image (k_lfc_fused); 129 takes the staged path"""
+    import torch
+    net = gpu_net("lfcW1A1", "mnist")
+    o = oracle("lfcW1A1", "mnist")
+    for kind in ("uniform", "sparse"):
+        imgs = rand_images("lfcW1A1", n, 30 + n, kind)
+        assert (net.raw(imgs) == o.words_fast(imgs)).all()
+        d = torch.from_numpy(imgs).cuda()
+        cls = torch.zeros(n, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        assert net.L.bnn_mi355x_inference_device(d.data_ptr(), n, 10, cls.data_ptr(), None, None, None) == 0
+        torch.cuda.synchronize()
+        assert cls.cpu().numpy().tolist() == o.classes_batched(imgs, 10).tolist()
+
+
 def test_lfc_device_decode():
     import torch
     net = gpu_net("lfcW1A1", "mnist")
