@@ -18,6 +18,7 @@ struct CnvLaunch {
   int number_class;
   hipStream_t stream;
   hipEvent_t *events;         // optional: kCnvStages+1 events, recorded around every stage
+  int last_stage;             // run stages 0..last_stage only (debug / per-layer tests); kCnvStages-1 = all
 };
 
 struct LfcLaunch {
@@ -30,12 +31,14 @@ struct LfcLaunch {
   int number_class;
   hipStream_t stream;
   hipEvent_t *events;         // optional: kLfcStages+1 events
+  int last_stage;             // run stages 0..last_stage only; kLfcStages-1 = all
 };
 
 constexpr int kCnvStages = 9;  // conv0, L1..L7, L8+decode
 constexpr int kLfcStages = 6;  // binarize, L0..L3, decode
 const char *stage_name(bool is_cnv, int stage);
 
+size_t stage_output_bytes(bool is_cnv, int abits, int stage, int *in_buf1);
 void cnv_workspace_bytes(int abits, size_t *buf0, size_t *buf1);
 void lfc_workspace_bytes(int abits, size_t *buf0, size_t *buf1);
 

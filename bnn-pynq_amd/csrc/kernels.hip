@@ -873,43 +873,43 @@ void run_cnv_t(const CnvLaunch &a) {
   BNN_MARK(a.events, 0, s);
   if (a.l0_mfma) {
     const dim3 g0((unsigned)((n * 900 + kBlock - 1) / kBlock));  // lane = pixel
-    BNN_LAUNCH((k_conv0_mfma<OUT2>), g0, s, a.images, A, a.l0_mfma, (int)(n * 900));
+    if (a.last_stage >= 0) BNN_LAUNCH((k_conv0_mfma<OUT2>), g0, s, a.images, A, a.l0_mfma, (int)(n * 900));
   } else {
-    BNN_LAUNCH((k_conv0<OUT2>), grid_for(n * 900, 2 / gpb_for(n * 900, 2)), s, a.images, A, a.rows[0], (int)(n * 900), 2, gpb_for(n * 900, 2));
+    if (a.last_stage >= 0) BNN_LAUNCH((k_conv0<OUT2>), grid_for(n * 900, 2 / gpb_for(n * 900, 2)), s, a.images, A, a.rows[0], (int)(n * 900), 2, gpb_for(n * 900, 2));
   }
   BNN_MARK(a.events, 1, s);
   if constexpr (ARITH == AR_XNOR && !OUT2) {
-    BNN_LAUNCH((k_quad_x<1, 30, true>), grid_for(n * 196, 2 / gpb_for(n * 196, 2)), s, A64, B, a.rows[1], (int)(n * 196), 2, gpb_for(n * 196, 2));
+    if (a.last_stage >= 1) BNN_LAUNCH((k_quad_x<1, 30, true>), grid_for(n * 196, 2 / gpb_for(n * 196, 2)), s, A64, B, a.rows[1], (int)(n * 196), 2, gpb_for(n * 196, 2));
     BNN_MARK(a.events, 2, s);
-    BNN_LAUNCH((k_quad_x<1, 14, false>), grid_for(n * 36, 4 / gpb_for(n * 36, 4)), s, B64, A, a.rows[2], (int)(n * 36), 4, gpb_for(n * 36, 4));
+    if (a.last_stage >= 2) BNN_LAUNCH((k_quad_x<1, 14, false>), grid_for(n * 36, 4 / gpb_for(n * 36, 4)), s, B64, A, a.rows[2], (int)(n * 36), 4, gpb_for(n * 36, 4));
     BNN_MARK(a.events, 3, s);
-    BNN_LAUNCH((k_quad_x<2, 12, true>), grid_for(n * 25, 4 / gpb_for(n * 25, 4)), s, A64, B, a.rows[3], (int)(n * 25), 4, gpb_for(n * 25, 4));
+    if (a.last_stage >= 3) BNN_LAUNCH((k_quad_x<2, 12, true>), grid_for(n * 25, 4 / gpb_for(n * 25, 4)), s, A64, B, a.rows[3], (int)(n * 25), 4, gpb_for(n * 25, 4));
     BNN_MARK(a.events, 4, s);
-    BNN_LAUNCH((k_vec_x<18, true, 2, 5>), grid_for(n * 9, 8 / gpb_for(n * 9, 8)), s, B64, A, a.rows[4], (int)(n * 9), 8, gpb_for(n * 9, 8));
+    if (a.last_stage >= 4) BNN_LAUNCH((k_vec_x<18, true, 2, 5>), grid_for(n * 9, 8 / gpb_for(n * 9, 8)), s, B64, A, a.rows[4], (int)(n * 9), 8, gpb_for(n * 9, 8));
     BNN_MARK(a.events, 5, s);
-    BNN_LAUNCH((k_vec_x<36, false, 1, 1>), grid_for(n, 8 / gpb_for(n, 8)), s, A64, B, a.rows[5], (int)n, 8, gpb_for(n, 8));
+    if (a.last_stage >= 5) BNN_LAUNCH((k_vec_x<36, false, 1, 1>), grid_for(n, 8 / gpb_for(n, 8)), s, A64, B, a.rows[5], (int)n, 8, gpb_for(n, 8));
     BNN_MARK(a.events, 6, s);
-    BNN_LAUNCH((k_vec_x<4, false, 1, 1>), grid_for(n, 16 / gpb_for(n, 16)), s, B64, A, a.rows[6], (int)n, 16, gpb_for(n, 16));
+    if (a.last_stage >= 6) BNN_LAUNCH((k_vec_x<4, false, 1, 1>), grid_for(n, 16 / gpb_for(n, 16)), s, B64, A, a.rows[6], (int)n, 16, gpb_for(n, 16));
     BNN_MARK(a.events, 7, s);
-    BNN_LAUNCH((k_vec_x<8, false, 1, 1>), grid_for(n, 16 / gpb_for(n, 16)), s, A64, B, a.rows[7], (int)n, 16, gpb_for(n, 16));
+    if (a.last_stage >= 7) BNN_LAUNCH((k_vec_x<8, false, 1, 1>), grid_for(n, 16 / gpb_for(n, 16)), s, A64, B, a.rows[7], (int)n, 16, gpb_for(n, 16));
     BNN_MARK(a.events, 8, s);
   } else {
-  BNN_LAUNCH((k_quad<ARITH, 1, 30, true, OUT2>), grid_for(n * 196, 2 / gpb_for(n * 196, 2)), s, A64, B, a.rows[1], (int)(n * 196), 2, gpb_for(n * 196, 2));
+  if (a.last_stage >= 1) BNN_LAUNCH((k_quad<ARITH, 1, 30, true, OUT2>), grid_for(n * 196, 2 / gpb_for(n * 196, 2)), s, A64, B, a.rows[1], (int)(n * 196), 2, gpb_for(n * 196, 2));
   BNN_MARK(a.events, 2, s);
-  BNN_LAUNCH((k_quad<ARITH, 1, 14, false, OUT2>), grid_for(n * 36, 4 / gpb_for(n * 36, 4)), s, B64, A, a.rows[2], (int)(n * 36), 4, gpb_for(n * 36, 4));
+  if (a.last_stage >= 2) BNN_LAUNCH((k_quad<ARITH, 1, 14, false, OUT2>), grid_for(n * 36, 4 / gpb_for(n * 36, 4)), s, B64, A, a.rows[2], (int)(n * 36), 4, gpb_for(n * 36, 4));
   BNN_MARK(a.events, 3, s);
-  BNN_LAUNCH((k_quad<ARITH, 2, 12, true, OUT2>), grid_for(n * 25, 4 / gpb_for(n * 25, 4)), s, A64, B, a.rows[3], (int)(n * 25), 4, gpb_for(n * 25, 4));
+  if (a.last_stage >= 3) BNN_LAUNCH((k_quad<ARITH, 2, 12, true, OUT2>), grid_for(n * 25, 4 / gpb_for(n * 25, 4)), s, A64, B, a.rows[3], (int)(n * 25), 4, gpb_for(n * 25, 4));
   BNN_MARK(a.events, 4, s);
-  BNN_LAUNCH((k_vec<ARITH, 18, OUT2, true, 2, 5>), grid_for(n * 9, 8 / gpb_for(n * 9, 8)), s, B64, A, a.rows[4], (int)(n * 9), 8, gpb_for(n * 9, 8));
+  if (a.last_stage >= 4) BNN_LAUNCH((k_vec<ARITH, 18, OUT2, true, 2, 5>), grid_for(n * 9, 8 / gpb_for(n * 9, 8)), s, B64, A, a.rows[4], (int)(n * 9), 8, gpb_for(n * 9, 8));
   BNN_MARK(a.events, 5, s);
-  BNN_LAUNCH((k_vec<ARITH, 36, OUT2, false, 1, 1>), grid_for(n, 8 / gpb_for(n, 8)), s, A64, B, a.rows[5], (int)n, 8, gpb_for(n, 8));
+  if (a.last_stage >= 5) BNN_LAUNCH((k_vec<ARITH, 36, OUT2, false, 1, 1>), grid_for(n, 8 / gpb_for(n, 8)), s, A64, B, a.rows[5], (int)n, 8, gpb_for(n, 8));
   BNN_MARK(a.events, 6, s);
-  BNN_LAUNCH((k_vec<ARITH, 4, OUT2, false, 1, 1>), grid_for(n, 16 / gpb_for(n, 16)), s, B64, A, a.rows[6], (int)n, 16, gpb_for(n, 16));
+  if (a.last_stage >= 6) BNN_LAUNCH((k_vec<ARITH, 4, OUT2, false, 1, 1>), grid_for(n, 16 / gpb_for(n, 16)), s, B64, A, a.rows[6], (int)n, 16, gpb_for(n, 16));
   BNN_MARK(a.events, 7, s);
-  BNN_LAUNCH((k_vec<ARITH, 8, OUT2, false, 1, 1>), grid_for(n, 16 / gpb_for(n, 16)), s, A64, B, a.rows[7], (int)n, 16, gpb_for(n, 16));
+  if (a.last_stage >= 7) BNN_LAUNCH((k_vec<ARITH, 8, OUT2, false, 1, 1>), grid_for(n, 16 / gpb_for(n, 16)), s, A64, B, a.rows[7], (int)n, 16, gpb_for(n, 16));
   BNN_MARK(a.events, 8, s);
   }
-  BNN_LAUNCH((k_fclast<ARITH, 8>), grid_for(n, 1), s, B64, a.scores, a.classes, a.rows[8], (int)n, a.number_class);
+  if (a.last_stage >= 8) BNN_LAUNCH((k_fclast<ARITH, 8>), grid_for(n, 1), s, B64, a.scores, a.classes, a.rows[8], (int)n, a.number_class);
   BNN_MARK(a.events, 9, s);
 }
 
@@ -921,6 +921,19 @@ const char *stage_name(bool is_cnv, int stage) {
   static const char *lfc[kLfcStages] = {"k_lfc_binarize", "k_vec L0", "k_vec L1", "k_vec L2", "k_vec L3", "k_lfc_decode"};
   if (stage < 0 || stage >= (is_cnv ? kCnvStages : kLfcStages)) return "";
   return is_cnv ? cnv[stage] : lfc[stage];
+}
+
+// bytes per image of the output of `stage` (what the next stage reads), and which buffer holds it
+size_t stage_output_bytes(bool is_cnv, int abits, int stage, int *in_buf1) {
+  static const size_t cnv[8] = {7200, 1568, 2304, 400, 288, 32, 64, 64};
+  if (is_cnv) {
+    if (stage < 0 || stage > 7) return 0;
+    *in_buf1 = stage & 1;
+    return cnv[stage] * (size_t)abits;
+  }
+  if (stage < 0 || stage > 3) return 0;
+  *in_buf1 = stage & 1;
+  return stage == 0 ? 104 : 128 * (size_t)abits;
 }
 
 // per-image bytes of the two ping-pong activation buffers
@@ -950,37 +963,37 @@ hipError_t run_lfc(NetId net, const LfcLaunch &a) {
   uint32_t *A = reinterpret_cast<uint32_t *>(a.buf0), *B = reinterpret_cast<uint32_t *>(a.buf1);
   uint64_t *A64 = reinterpret_cast<uint64_t *>(a.buf0), *B64 = reinterpret_cast<uint64_t *>(a.buf1);
   hipStream_t s = a.stream;
-  if (net == NET_LFCW1A1 && n <= kLfcFusedMax && !a.events) {
+  if (net == NET_LFCW1A1 && n <= kLfcFusedMax && !a.events && a.last_stage >= kLfcStages - 1) {
     // small batch: the one-launch, block-per-image form (no per-stage events: there are no stages)
     hipLaunchKernelGGL(k_lfc_fused, dim3((unsigned)n), dim3(1024), 0, s, a.images, a.words, a.classes, a.rows[0], a.rows[1],
                        a.rows[2], a.rows[3], a.number_class);
     return hipGetLastError();
   }
   BNN_MARK(a.events, 0, s);
-  BNN_LAUNCH(k_lfc_binarize, grid_for(n * 13, 1), s, a.images, A64, (int)(n * 13));
+  if (a.last_stage >= 0) BNN_LAUNCH(k_lfc_binarize, grid_for(n * 13, 1), s, a.images, A64, (int)(n * 13));
   BNN_MARK(a.events, 1, s);
   if (net == NET_LFCW1A1) {
-    BNN_LAUNCH((k_vec_x<13, false, 1, 1>), grid_for(n, 32 / gpb_for(n, 32)), s, A64, B, a.rows[0], (int)n, 32, gpb_for(n, 32));
+    if (a.last_stage >= 1) BNN_LAUNCH((k_vec_x<13, false, 1, 1>), grid_for(n, 32 / gpb_for(n, 32)), s, A64, B, a.rows[0], (int)n, 32, gpb_for(n, 32));
     BNN_MARK(a.events, 2, s);
-    BNN_LAUNCH((k_vec_x<16, false, 1, 1>), grid_for(n, 32 / gpb_for(n, 32)), s, B64, A, a.rows[1], (int)n, 32, gpb_for(n, 32));
+    if (a.last_stage >= 2) BNN_LAUNCH((k_vec_x<16, false, 1, 1>), grid_for(n, 32 / gpb_for(n, 32)), s, B64, A, a.rows[1], (int)n, 32, gpb_for(n, 32));
     BNN_MARK(a.events, 3, s);
-    BNN_LAUNCH((k_vec_x<16, false, 1, 1>), grid_for(n, 32 / gpb_for(n, 32)), s, A64, B, a.rows[2], (int)n, 32, gpb_for(n, 32));
+    if (a.last_stage >= 3) BNN_LAUNCH((k_vec_x<16, false, 1, 1>), grid_for(n, 32 / gpb_for(n, 32)), s, A64, B, a.rows[2], (int)n, 32, gpb_for(n, 32));
     BNN_MARK(a.events, 4, s);
-    BNN_LAUNCH((k_vec_x<16, false, 1, 1>), grid_for(n, 2 / gpb_for(n, 2)), s, B64, reinterpret_cast<uint32_t *>(a.words), a.rows[3], (int)n, 2, gpb_for(n, 2));
+    if (a.last_stage >= 4) BNN_LAUNCH((k_vec_x<16, false, 1, 1>), grid_for(n, 2 / gpb_for(n, 2)), s, B64, reinterpret_cast<uint32_t *>(a.words), a.rows[3], (int)n, 2, gpb_for(n, 2));
     BNN_MARK(a.events, 5, s);
   } else if (net == NET_LFCW1A2) {
-    BNN_LAUNCH((k_vec<AR_XNOR, 13, true, false, 1, 1>), grid_for(n, 32 / gpb_for(n, 32)), s, A64, B, a.rows[0], (int)n, 32, gpb_for(n, 32));
+    if (a.last_stage >= 1) BNN_LAUNCH((k_vec<AR_XNOR, 13, true, false, 1, 1>), grid_for(n, 32 / gpb_for(n, 32)), s, A64, B, a.rows[0], (int)n, 32, gpb_for(n, 32));
     BNN_MARK(a.events, 2, s);
-    BNN_LAUNCH((k_vec<AR_TB, 16, true, false, 1, 1>), grid_for(n, 32 / gpb_for(n, 32)), s, B64, A, a.rows[1], (int)n, 32, gpb_for(n, 32));
+    if (a.last_stage >= 2) BNN_LAUNCH((k_vec<AR_TB, 16, true, false, 1, 1>), grid_for(n, 32 / gpb_for(n, 32)), s, B64, A, a.rows[1], (int)n, 32, gpb_for(n, 32));
     BNN_MARK(a.events, 3, s);
-    BNN_LAUNCH((k_vec<AR_TB, 16, true, false, 1, 1>), grid_for(n, 32 / gpb_for(n, 32)), s, A64, B, a.rows[2], (int)n, 32, gpb_for(n, 32));
+    if (a.last_stage >= 3) BNN_LAUNCH((k_vec<AR_TB, 16, true, false, 1, 1>), grid_for(n, 32 / gpb_for(n, 32)), s, A64, B, a.rows[2], (int)n, 32, gpb_for(n, 32));
     BNN_MARK(a.events, 4, s);
-    BNN_LAUNCH((k_vec<AR_TB, 16, false, false, 1, 1>), grid_for(n, 2 / gpb_for(n, 2)), s, B64, reinterpret_cast<uint32_t *>(a.words), a.rows[3], (int)n, 2, gpb_for(n, 2));
+    if (a.last_stage >= 4) BNN_LAUNCH((k_vec<AR_TB, 16, false, false, 1, 1>), grid_for(n, 2 / gpb_for(n, 2)), s, B64, reinterpret_cast<uint32_t *>(a.words), a.rows[3], (int)n, 2, gpb_for(n, 2));
     BNN_MARK(a.events, 5, s);
   } else {
     return hipErrorInvalidValue;
   }
-  if (a.classes) BNN_LAUNCH(k_lfc_decode, grid_for(n, 1), s, a.words, a.classes, (int)n, a.number_class);
+  if (a.classes && a.last_stage >= 5) BNN_LAUNCH(k_lfc_decode, grid_for(n, 1), s, a.words, a.classes, (int)n, a.number_class);
   BNN_MARK(a.events, 6, s);
   return hipGetLastError();
 }

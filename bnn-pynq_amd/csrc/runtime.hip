@@ -48,6 +48,7 @@ struct Runtime {
   std::vector<uint8_t> blob;
   void *d_blob = nullptr;
   uint64_t fault_seed = 0;  // 0: std::random_device, like the reference
+  int debug_last_stage = -1;  // >= 0: stop after this stage (bnn_mi355x_debug_stage_output)
   std::vector<Fault> last_faults;
   const uint32_t *rows[9] = {};
   const uint8_t *l0_mfma = nullptr;  // layer 0 as an MFMA operand (CNV nets), unless BNN_MI355X_L0=valu
@@ -201,6 +202,7 @@ int enqueue(const uint8_t *d_imgs, int n, int ncls, int32_t *d_classes, int16_t 
     for (int l = 0; l < 9; l++) a.rows[l] = r.rows[l];
     a.l0_mfma = r.l0_mfma;
     a.scores = d_scores; a.classes = d_classes; a.number_class = ncls; a.stream = s; a.events = evs;
+    a.last_stage = r.debug_last_stage >= 0 ? r.debug_last_stage : kCnvStages - 1;
     e = run_cnv(r.spec.id, a);
   } else {
     LfcLaunch a{};
@@ -208,6 +210,7 @@ int enqueue(const uint8_t *d_imgs, int n, int ncls, int32_t *d_classes, int16_t 
     for (int l = 0; l < 4; l++) a.rows[l] = r.rows[l];
     a.words = d_words;
     a.classes = d_classes; a.number_class = ncls; a.stream = s; a.events = evs;
+    a.last_stage = r.debug_last_stage >= 0 ? r.debug_last_stage : kLfcStages - 1;
     e = run_lfc(r.spec.id, a);
   }
   if (e != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(e));
@@ -538,6 +541,22 @@ int bnn_mi355x_inference_raw(const uint8_t *images, int n_images, int16_t *score
 }
 
 int bnn_mi355x_reserve(int max_images) { return ready() ? reserve(max_images) : -1; }
+
+long bnn_mi355x_debug_stage_output(const uint8_t *images, int n_images, int stage, void *dst, size_t cap) {
+  Runtime &r = rt();
+  if (!ready()) return -1;
+  int in_buf1 = 0;
+  const size_t per = stage_output_bytes(r.spec.is_cnv, r.spec.abits, stage, &in_buf1);
+  if (per == 0 || n_images <= 0 || n_images > kHostChunk || !images || !dst || cap < per * (size_t)n_images)
+    return fail("debug_stage_output: bad arguments");
+  r.debug_last_stage = stage;
+  std::vector<uint64_t> w((size_t)n_images);
+  const int rc = infer_host(images, n_images, 10, nullptr, nullptr, r.spec.is_cnv ? nullptr : w.data(), nullptr);
+  r.debug_last_stage = -1;
+  if (rc) return -1;
+  HIP_OK(hipMemcpy(dst, in_buf1 ? r.buf1 : r.buf0, per * (size_t)n_images, hipMemcpyDeviceToHost));
+  return (long)per;
+}
 
 int bnn_mi355x_plan_faults(unsigned long long seed, int num_images, unsigned int flip_count, int word_size, int target,
                            const int *target_layers, unsigned int num_targets, int *records, int cap_records) {

@@ -132,6 +132,12 @@ int bnn_mi355x_plan_faults(unsigned long long seed, int num_images, unsigned int
                            const int *target_layers, unsigned int num_targets, int *records, int cap_records);
 size_t bnn_mi355x_pack_params_faulty(const char *path, const int *records, int n_faults, void *dst, size_t cap);
 
+/* Test hook: run the stages 0..stage on n host images (n <= 32768) and copy that stage's output,
+ * exactly as it sits in HBM (bit-packed activation layout), to dst.  CNV: stage L =
+ * layer L (0..7, after the max-pool where there is one); LFC: stage 0 = binarised input, stage
+ * L+1 = layer L (L <= 2).  Returns the bytes per image, or -1. */
+long bnn_mi355x_debug_stage_output(const uint8_t *images, int n_images, int stage, void *dst, size_t cap);
+
 /* Per-stage device timing with HIP events on the stream the kernels run on
  * (used by bench.py for the roofline line).  profile(1) makes every later
  * inference call bracket each stage with events; profile_read waits for them,

@@ -16,7 +16,7 @@ EXT = ["bnn_mi355x_network", "bnn_mi355x_image_bytes", "bnn_mi355x_last_error", 
        "bnn_mi355x_pack_params", "bnn_mi355x_export_params", "bnn_mi355x_import_params",
        "bnn_mi355x_inference_buffer", "bnn_mi355x_inference_raw", "bnn_mi355x_inference_device",
        "bnn_mi355x_reserve", "bnn_mi355x_set_fault_seed", "bnn_mi355x_last_faults", "bnn_mi355x_plan_faults",
-       "bnn_mi355x_pack_params_faulty", "bnn_mi355x_profile", "bnn_mi355x_profile_read", "bnn_mi355x_stage_name"]
+       "bnn_mi355x_pack_params_faulty", "bnn_mi355x_debug_stage_output", "bnn_mi355x_profile", "bnn_mi355x_profile_read", "bnn_mi355x_stage_name"]
 
 
 def lib_path(network, runtime="python_sw"):
@@ -64,6 +64,8 @@ def load(network, runtime="python_sw"):
     L.bnn_mi355x_plan_faults.argtypes = [C.c_ulonglong, C.c_int, C.c_uint, C.c_int, C.c_int, ip, C.c_uint, ip, C.c_int]
     L.bnn_mi355x_pack_params_faulty.argtypes = [C.c_char_p, ip, C.c_int, C.c_void_p, C.c_size_t]
     L.bnn_mi355x_pack_params_faulty.restype = C.c_size_t
+    L.bnn_mi355x_debug_stage_output.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    L.bnn_mi355x_debug_stage_output.restype = C.c_long
     L.bnn_mi355x_profile.argtypes = [C.c_int]
     L.bnn_mi355x_profile_read.argtypes = [fp, C.c_int, ip]
     L.bnn_mi355x_stage_name.argtypes = [C.c_int]

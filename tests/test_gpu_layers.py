@@ -1,0 +1,71 @@
+"""GPU, per-kernel parity: the output of EVERY stage -- sliding-window + MVAU +
+threshold (+ max-pool) -- as it sits bit-packed in HBM, against the faithful scalar restatement's
+activations after the same layer, for all five networks, shipped and random parameters."""
+import numpy as np
+import pytest
+
+import gpu_lib as gl
+import oracle_lib as ol
+
+pytestmark = pytest.mark.gpu
+
+NETS = [("cnvW1A1", "cifar10"), ("cnvW1A2", "cifar10"), ("cnvW2A2", "cifar10"), ("lfcW1A1", "mnist"), ("lfcW1A2", "mnist")]
+CNV_SHAPE = [(900, 64), (196, 64), (144, 128), (25, 128), (9, 256), (1, 256), (1, 512), (1, 512)]  # pixels, channels
+
+
+def unpack(raw, pixels, channels, planes):
+    """HBM layout -> value-domain array [pixels * channels] (pixel-major, like oracle.layer_ref)"""
+    if planes == 1:   # [pixel][C/32] dwords, bit c = fired (+1)
+        bits = np.unpackbits(raw.view(np.uint8), bitorder="little").reshape(pixels, channels)
+        return np.where(bits == 1, 1, -1).astype(np.int8).reshape(-1)
+    w = raw.view(np.uint64).reshape(pixels, channels // 64, 2)      # [pixel][C/64][sign, non-zero]
+    sign = np.unpackbits(np.ascontiguousarray(w[:, :, 0]).view(np.uint8), bitorder="little").reshape(pixels, channels)
+    nz = np.unpackbits(np.ascontiguousarray(w[:, :, 1]).view(np.uint8), bitorder="little").reshape(pixels, channels)
+    return np.where(nz == 1, np.where(sign == 1, -1, 1), 0).astype(np.int8).reshape(-1)
+
+
+def stage_output(L, imgs, stage):
+    n = imgs.shape[0]
+    buf = np.zeros(n * 16384, np.uint8)
+    per = L.bnn_mi355x_debug_stage_output(imgs.ctypes.data, n, stage, buf.ctypes.data, buf.size)
+    assert per > 0, L.bnn_mi355x_last_error()
+    return buf[: n * per].reshape(n, per)
+
+
+def check_all_stages(network, pdir, seed):
+    L = gl.load(network)
+    L.load_parameters(pdir.encode())
+    assert L.bnn_mi355x_last_error() == b""
+    o = ol.Oracle(network, pdir)
+    planes = 2 if network.endswith("A2") else 1
+    rng = np.random.default_rng(seed)
+    if o.is_cnv:
+        imgs = rng.integers(0, 256, (3, 3072), dtype=np.uint8)
+        for stage, (pixels, channels) in enumerate(CNV_SHAPE):
+            raw = stage_output(L, imgs, stage)
+            for i in range(len(imgs)):
+                want = o.layer_ref(imgs[i], stage)
+                got = unpack(raw[i], pixels, channels, planes)
+                assert got.size == want.size and (got == want).all(), "stage %d image %d" % (stage, i)
+    else:
+        imgs = rng.integers(0, 256, (40, 784), dtype=np.uint8)
+        raw = stage_output(L, imgs, 0)                              # binarizeAndPack
+        bits = np.unpackbits(raw, axis=1, bitorder="little")
+        assert (bits[:, :784] == (imgs >= 128)).all() and (bits[:, 784:] == 0).all()
+        for layer in range(3):
+            raw = stage_output(L, imgs, layer + 1)
+            for i in range(len(imgs)):
+                assert (unpack(raw[i], 1, 1024, planes) == o.layer_ref(imgs[i], layer)).all(), "layer %d image %d" % (layer, i)
+
+
+@pytest.mark.parametrize("network,dataset", NETS, ids=lambda x: x)
+def test_every_stage_shipped_params(network, dataset):
+    check_all_stages(network, gl.param_dir(dataset, network), 41)
+
+
+@pytest.mark.parametrize("network,dataset", NETS, ids=lambda x: x)
+def test_every_stage_random_params(network, dataset, tmp_path):
+    import random_params
+    random_params.make(str(tmp_path), network, 9)
+    check_all_stages(network, str(tmp_path), 42)
+    gl.load(network).load_parameters(gl.param_dir(dataset, network).encode())   # leave the library as found
