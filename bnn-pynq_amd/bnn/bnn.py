@@ -28,6 +28,8 @@ import tempfile
 
 import numpy as np
 
+from . import abi
+
 try:  # the reference imports PIL unconditionally; keep the module importable without it
     from PIL import Image
 except ImportError:  # pragma: no cover
@@ -53,10 +55,10 @@ NETWORK_LFCW1A2_INTERLEAVED = "lfcW1A2-interleaved"
 
 # The reference derives PLATFORM from $BOARD (Ultra96 / Pynq-Z1 / Pynq-Z2); a GPU
 # host has no such variable.  BNN_PLATFORM overrides the directory name.
-PLATFORM = os.environ.get("BNN_PLATFORM", "mi355x")
+PLATFORM = abi.PLATFORM
 
 BNN_ROOT_DIR = os.path.dirname(os.path.realpath(__file__))
-BNN_LIB_DIR = os.path.join(BNN_ROOT_DIR, "libraries", PLATFORM)
+BNN_LIB_DIR = abi.LIB_DIR
 BNN_BIT_DIR = os.path.join(BNN_ROOT_DIR, "bitstreams", PLATFORM)  # kept for name compatibility; unused
 BNN_PARAM_DIR = os.path.join(BNN_ROOT_DIR, "params")
 
@@ -73,46 +75,10 @@ void deinit();
 _libraries = {}
 
 
-class _CtypesInterface:
-    """ABI-mode binding of the six reference symbols (+ extensions) via ctypes."""
-
-    def __init__(self, path):
-        lib = ctypes.CDLL(path)
-        c_int_p = ctypes.POINTER(ctypes.c_int)
-        c_float_p = ctypes.POINTER(ctypes.c_float)
-        lib.load_parameters.argtypes = [ctypes.c_char_p]
-        lib.load_parameters.restype = None
-        lib.inference.argtypes = [ctypes.c_char_p, c_int_p, ctypes.c_int, c_float_p]
-        lib.inference.restype = ctypes.c_int
-        lib.inference_multiple.argtypes = [ctypes.c_char_p, ctypes.c_int, c_int_p, c_float_p, ctypes.c_int]
-        lib.inference_multiple.restype = c_int_p
-        lib.inference_multiple_with_faults.argtypes = [
-            ctypes.c_char_p, ctypes.c_int, c_int_p, c_float_p, ctypes.c_uint, ctypes.c_int, ctypes.c_int,
-            c_int_p, ctypes.c_uint]
-        lib.inference_multiple_with_faults.restype = c_int_p
-        lib.free_results.argtypes = [c_int_p]
-        lib.free_results.restype = None
-        lib.deinit.argtypes = []
-        lib.deinit.restype = None
-        self.has_ext = hasattr(lib, "bnn_mi355x_inference_buffer")
-        if self.has_ext:
-            lib.bnn_mi355x_inference_buffer.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, c_float_p,
-                                                        ctypes.c_int]
-            lib.bnn_mi355x_inference_buffer.restype = c_int_p
-            lib.bnn_mi355x_image_bytes.restype = ctypes.c_int
-            lib.bnn_mi355x_last_error.restype = ctypes.c_char_p
-        self.lib = lib
-
-
 def _open_library(dllname):
-    """dlopen once per process and name, like the reference's _libraries cache."""
+    """dlopen once per process and name, like the reference's _libraries cache"""
     if dllname not in _libraries:
-        path = os.path.join(BNN_LIB_DIR, dllname)
-        if not os.path.exists(path):
-            raise RuntimeError(
-                "runtime library %s not found: build it with `make -C bnn-pynq_amd` "
-                "(the MI355X runtime has no CPU fallback)" % path)
-        _libraries[dllname] = _CtypesInterface(path)
+        _libraries[dllname] = abi.load_path(os.path.join(BNN_LIB_DIR, dllname))
     return _libraries[dllname]
 
 
@@ -134,8 +100,7 @@ class PynqBNN:
         # MI355X both runtime names resolve to the same HIP library.
         self.bitstream_name = None
         dllname = "{0}-{1}-{2}.so".format(runtime, network, PLATFORM)
-        self._iface = _open_library(dllname)
-        self.interface = self._iface.lib
+        self.interface = _open_library(dllname)
         self.num_classes = 0
         self.classes = []
         self.usecPerImage = 0.0
@@ -226,7 +191,7 @@ class PynqBNN:
     # -- extension: images already in memory ----------------------------------
     def inference_array(self, images, detail=False):
         """images: uint8 array, n x 3072 (planar CHW) for cnv*, n x 784 for lfc*"""
-        if not self._iface.has_ext:
+        if not self.interface.has_extensions:
             raise RuntimeError("this runtime library has no in-memory entry point")
         isz = self.interface.bnn_mi355x_image_bytes()
         a = np.ascontiguousarray(images, dtype=np.uint8).reshape(-1, isz)

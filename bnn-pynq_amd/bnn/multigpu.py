@@ -5,13 +5,11 @@ the one-time broadcast of the packed parameter blob; shards are contiguous range
 no per-layer communication exists.
 
     dist.init_process_group("nccl"); torch.cuda.set_device(local_rank)
-    lib = <ctypes handle of libraries/mi355x/python_sw-cnvW1A1-mi355x.so>
+    lib = bnn.abi.load("cnvW1A1")          # ctypes handle with the ABI declared
     lib.bnn_mi355x_set_device(local_rank)
     distribute_params(lib, "/path/to/params/cifar10/cnvW1A1")   # rank 0 reads the files
     lo, hi = shard_bounds(n_images, world)[rank]
 """
-import ctypes
-
 import numpy as np
 
 
@@ -28,9 +26,6 @@ def shard_bounds(n_items, world_size):
 
 def pack_params(lib, param_dir):
     """param directory -> packed blob (numpy uint8).  Host only: touches no GPU."""
-    lib.bnn_mi355x_pack_params.restype = ctypes.c_size_t
-    lib.bnn_mi355x_pack_params.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t]
-    lib.bnn_mi355x_last_error.restype = ctypes.c_char_p
     n = lib.bnn_mi355x_pack_params(param_dir.encode(), None, 0)
     if n == 0:
         raise RuntimeError(lib.bnn_mi355x_last_error().decode())
@@ -66,9 +61,7 @@ def distribute_params(lib, param_dir, device=None, group=None, upload=True):
     blob = pack_params(lib, param_dir) if rank == 0 else None
     blob = broadcast_blob(blob, 0, device, group)
     if upload:
-        lib.bnn_mi355x_import_params.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
         if lib.bnn_mi355x_import_params(blob.ctypes.data, blob.size) != 0:
-            lib.bnn_mi355x_last_error.restype = ctypes.c_char_p
             raise RuntimeError(lib.bnn_mi355x_last_error().decode())
     return blob
 
