@@ -209,7 +209,7 @@ def main():
            else "images/sec (whole node) %s batch" % a.network,
            "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "u1 (1-bit XNOR-popcount; int8 first layer on v_mfma_i32_i8)", "data": "synthetic",
+           "vs_baseline": None, "dtype": "u1" if a.network.endswith("A1") else "u2", "dtype_note": "bit-packed XNOR/AND + popcount on the integer VALU; the int8 first layer of the CNV nets on v_mfma_i32_32x32x32_i8", "data": "synthetic",
            "config": {"workload": "%s, %d synthetic %s images per GPU per step, inputs resident in HBM, params %s/%s"
                       % (a.network, a.batch, "32x32x3 uint8" if is_cnv else "28x28 uint8", dataset, a.network),
                       "images_per_gpu_per_step": a.batch, "parallelism": "dp%d (batch shards, no data-path collective)" % world},
