@@ -101,6 +101,7 @@ def main():
         sys.exit("bench.py needs a GPU: the product has no CPU path")
     if a.rehearse_gloo:
         local_rank = 0
+    local_rank %= max(torch.cuda.device_count(), 1)   # a launcher may expose one device per rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
