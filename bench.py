@@ -111,6 +111,11 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
+    if not os.path.exists(gl.lib_path(a.network)) and rank == 0:
+        import subprocess  # a checkout without the built libraries: build them once (hipcc is in the image)
+        subprocess.run(["make", "-s", "-j8", "-C", os.path.join(ROOT, "bnn-pynq_amd")], check=True)
+    if world > 1:
+        dist.barrier()
     L = gl.load(a.network)
     assert L.bnn_mi355x_set_device(local_rank) == 0
 
