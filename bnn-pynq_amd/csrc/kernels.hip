@@ -360,7 +360,16 @@ __device__ __forceinline__ int xpop0(uint32_t w, uint32_t a) {
   asm("" : "+v"(acc));
   return acc;
 }
-template <int CW, int ID, bool POOL>
+// result of one neuron group of one pixel/vector: a whole dword (32 neurons per block, the
+// throughput form) or one byte of it (8 neurons per block: four times as many, four times shorter
+// blocks -- small batches, where the 32-neuron form leaves most of the chip idle)
+template <int NPB>
+__device__ __forceinline__ void store_group(uint32_t *__restrict__ out, size_t index, uint32_t bits) {
+  if constexpr (NPB == 32) out[index] = bits;
+  else reinterpret_cast<uint8_t *>(out)[index] = (uint8_t)bits;
+}
+
+template <int CW, int ID, bool POOL, int NPB = 32>
 __global__ __launch_bounds__(kBlock) void k_quad_x(const uint64_t *__restrict__ in, uint32_t *__restrict__ out,
                                                     const uint32_t *__restrict__ rows, int n_items, int groups, int gpb) {
   constexpr int OD = ID - 2, QD = OD / 2, NQ = QD * QD, KW = 9 * CW, ROW_DW = 2 + 2 * KW;
@@ -382,9 +391,9 @@ __global__ __launch_bounds__(kBlock) void k_quad_x(const uint64_t *__restrict__ 
         wh[y][x][k] = (uint32_t)(v >> 32);
       }
   for (int cg = bm.cg * gpb, cg_end = cg + gpb; cg < cg_end; cg++) {  // see k_conv0
-    kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)cg * 32 * ROW_DW);
+    kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)cg * NPB * ROW_DW);
     uint32_t b[4] = {0, 0, 0, 0};
-    for (int c = 31; c >= 0; c--) {
+    for (int c = NPB - 1; c >= 0; c--) {
       kptr32 r = w + c * ROW_DW;
       const int t = (int)r[0];
       int m[2][2] = {{0, 0}, {0, 0}};
@@ -404,12 +413,12 @@ __global__ __launch_bounds__(kBlock) void k_quad_x(const uint64_t *__restrict__ 
       }
     }
     if constexpr (POOL) {
-      out[(size_t)item * groups + cg] = b[0];
+      store_group<NPB>(out, (size_t)item * groups + cg, b[0]);
     } else {
   #pragma unroll
       for (int i = 0; i < 4; i++) {
         const size_t pix = (size_t)img * OD * OD + (size_t)(2 * qy + (i >> 1)) * OD + 2 * qx + (i & 1);
-        out[pix * groups + cg] = b[i];
+        store_group<NPB>(out, pix * groups + cg, b[i]);
       }
     }
   }
@@ -417,7 +426,7 @@ __global__ __launch_bounds__(kBlock) void k_quad_x(const uint64_t *__restrict__ 
 
 // one lane = one vector of KW words (FC layers, CNV layer 5; SINGLE: CNV layer 4 window gather).
 // Two neurons per iteration: two independent v_bcnt chains per lane.
-template <int KW, bool SINGLE, int CW, int ID>
+template <int KW, bool SINGLE, int CW, int ID, int NPB = 32>
 __global__ __launch_bounds__(kBlock) void k_vec_x(const uint64_t *__restrict__ in, uint32_t *__restrict__ out,
                                                    const uint32_t *__restrict__ rows, int n_items, int groups, int gpb) {
   constexpr int ROW_DW = 2 + 2 * KW;
@@ -451,9 +460,9 @@ __global__ __launch_bounds__(kBlock) void k_vec_x(const uint64_t *__restrict__ i
     }
   }
   for (int cg = bm.cg * gpb, cg_end = cg + gpb; cg < cg_end; cg++) {  // see k_conv0
-    kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)cg * 32 * ROW_DW);
+    kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)cg * NPB * ROW_DW);
     uint32_t b = 0;
-    for (int c = 31; c >= 0; c -= 2) {
+    for (int c = NPB - 1; c >= 0; c -= 2) {
       kptr32 r1 = w + c * ROW_DW, r0 = r1 - ROW_DW;
       int m1 = xpop0(r1[2], al[0]), m0 = xpop0(r0[2], al[0]);
       xpop(m1, r1[3], ah[0]);
@@ -468,7 +477,7 @@ __global__ __launch_bounds__(kBlock) void k_vec_x(const uint64_t *__restrict__ i
       b = shift_in_sign(b, m1 - (int)r1[0]);
       b = shift_in_sign(b, m0 - (int)r0[0]);
     }
-    out[(size_t)item * groups + cg] = b;
+    store_group<NPB>(out, (size_t)item * groups + cg, b);
   }
 }
 
@@ -849,6 +858,10 @@ __global__ __launch_bounds__(kBlock) void k_lfc_decode(const uint64_t *__restric
 // so that a lane writes whole output words and reads its window once; otherwise one (parallelism first)
 inline int gpb_for(long long items, int groups) { return (items + kBlock - 1) / kBlock >= 2048 ? groups : 1; }
 
+// small batches: 8 neurons per block instead of 32 while the 32-neuron grid would not even give
+// every SIMD of the chip two waves (256 CUs x 4 SIMDs x 2 / 4 waves per block)
+inline bool narrow_for(long long items, int groups32) { return ((items + kBlock - 1) / kBlock) * groups32 < 512; }
+
 inline dim3 grid_for(long long items, int groups) {  // matches map_block()
   const long long item_blocks = (items + kBlock - 1) / kBlock;
   return dim3((unsigned)(((item_blocks + 7) / 8) * 8 * groups));
@@ -879,19 +892,54 @@ void run_cnv_t(const CnvLaunch &a) {
   }
   BNN_MARK(a.events, 1, s);
   if constexpr (ARITH == AR_XNOR && !OUT2) {
-    if (a.last_stage >= 1) BNN_LAUNCH((k_quad_x<1, 30, true>), grid_for(n * 196, 2 / gpb_for(n * 196, 2)), s, A64, B, a.rows[1], (int)(n * 196), 2, gpb_for(n * 196, 2));
+    if (a.last_stage >= 1) {
+      if (narrow_for(n * 196, 2))
+        BNN_LAUNCH((k_quad_x<1, 30, true, 8>), grid_for(n * 196, 8), s, A64, B, a.rows[1], (int)(n * 196), 8, 1);
+      else
+        BNN_LAUNCH((k_quad_x<1, 30, true>), grid_for(n * 196, 2 / gpb_for(n * 196, 2)), s, A64, B, a.rows[1], (int)(n * 196), 2, gpb_for(n * 196, 2));
+    }
     BNN_MARK(a.events, 2, s);
-    if (a.last_stage >= 2) BNN_LAUNCH((k_quad_x<1, 14, false>), grid_for(n * 36, 4 / gpb_for(n * 36, 4)), s, B64, A, a.rows[2], (int)(n * 36), 4, gpb_for(n * 36, 4));
+    if (a.last_stage >= 2) {
+      if (narrow_for(n * 36, 4))
+        BNN_LAUNCH((k_quad_x<1, 14, false, 8>), grid_for(n * 36, 16), s, B64, A, a.rows[2], (int)(n * 36), 16, 1);
+      else
+        BNN_LAUNCH((k_quad_x<1, 14, false>), grid_for(n * 36, 4 / gpb_for(n * 36, 4)), s, B64, A, a.rows[2], (int)(n * 36), 4, gpb_for(n * 36, 4));
+    }
     BNN_MARK(a.events, 3, s);
-    if (a.last_stage >= 3) BNN_LAUNCH((k_quad_x<2, 12, true>), grid_for(n * 25, 4 / gpb_for(n * 25, 4)), s, A64, B, a.rows[3], (int)(n * 25), 4, gpb_for(n * 25, 4));
+    if (a.last_stage >= 3) {
+      if (narrow_for(n * 25, 4))
+        BNN_LAUNCH((k_quad_x<2, 12, true, 8>), grid_for(n * 25, 16), s, A64, B, a.rows[3], (int)(n * 25), 16, 1);
+      else
+        BNN_LAUNCH((k_quad_x<2, 12, true>), grid_for(n * 25, 4 / gpb_for(n * 25, 4)), s, A64, B, a.rows[3], (int)(n * 25), 4, gpb_for(n * 25, 4));
+    }
     BNN_MARK(a.events, 4, s);
-    if (a.last_stage >= 4) BNN_LAUNCH((k_vec_x<18, true, 2, 5>), grid_for(n * 9, 8 / gpb_for(n * 9, 8)), s, B64, A, a.rows[4], (int)(n * 9), 8, gpb_for(n * 9, 8));
+    if (a.last_stage >= 4) {
+      if (narrow_for(n * 9, 8))
+        BNN_LAUNCH((k_vec_x<18, true, 2, 5, 8>), grid_for(n * 9, 32), s, B64, A, a.rows[4], (int)(n * 9), 32, 1);
+      else
+        BNN_LAUNCH((k_vec_x<18, true, 2, 5>), grid_for(n * 9, 8 / gpb_for(n * 9, 8)), s, B64, A, a.rows[4], (int)(n * 9), 8, gpb_for(n * 9, 8));
+    }
     BNN_MARK(a.events, 5, s);
-    if (a.last_stage >= 5) BNN_LAUNCH((k_vec_x<36, false, 1, 1>), grid_for(n, 8 / gpb_for(n, 8)), s, A64, B, a.rows[5], (int)n, 8, gpb_for(n, 8));
+    if (a.last_stage >= 5) {
+      if (narrow_for(n, 8))
+        BNN_LAUNCH((k_vec_x<36, false, 1, 1, 8>), grid_for(n, 32), s, A64, B, a.rows[5], (int)(n), 32, 1);
+      else
+        BNN_LAUNCH((k_vec_x<36, false, 1, 1>), grid_for(n, 8 / gpb_for(n, 8)), s, A64, B, a.rows[5], (int)(n), 8, gpb_for(n, 8));
+    }
     BNN_MARK(a.events, 6, s);
-    if (a.last_stage >= 6) BNN_LAUNCH((k_vec_x<4, false, 1, 1>), grid_for(n, 16 / gpb_for(n, 16)), s, B64, A, a.rows[6], (int)n, 16, gpb_for(n, 16));
+    if (a.last_stage >= 6) {
+      if (narrow_for(n, 16))
+        BNN_LAUNCH((k_vec_x<4, false, 1, 1, 8>), grid_for(n, 64), s, B64, A, a.rows[6], (int)(n), 64, 1);
+      else
+        BNN_LAUNCH((k_vec_x<4, false, 1, 1>), grid_for(n, 16 / gpb_for(n, 16)), s, B64, A, a.rows[6], (int)(n), 16, gpb_for(n, 16));
+    }
     BNN_MARK(a.events, 7, s);
-    if (a.last_stage >= 7) BNN_LAUNCH((k_vec_x<8, false, 1, 1>), grid_for(n, 16 / gpb_for(n, 16)), s, A64, B, a.rows[7], (int)n, 16, gpb_for(n, 16));
+    if (a.last_stage >= 7) {
+      if (narrow_for(n, 16))
+        BNN_LAUNCH((k_vec_x<8, false, 1, 1, 8>), grid_for(n, 64), s, A64, B, a.rows[7], (int)(n), 64, 1);
+      else
+        BNN_LAUNCH((k_vec_x<8, false, 1, 1>), grid_for(n, 16 / gpb_for(n, 16)), s, A64, B, a.rows[7], (int)(n), 16, gpb_for(n, 16));
+    }
     BNN_MARK(a.events, 8, s);
   } else {
   if (a.last_stage >= 1) BNN_LAUNCH((k_quad<ARITH, 1, 30, true, OUT2>), grid_for(n * 196, 2 / gpb_for(n * 196, 2)), s, A64, B, a.rows[1], (int)(n * 196), 2, gpb_for(n * 196, 2));
