@@ -77,6 +77,7 @@ def parse():
     ap.add_argument("--dataset", default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target length of the CPU baseline leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and integer-pipe-first-layer side measurements")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="multi-rank dry run on ONE GPU: gloo instead of RCCL, every rank computes on cuda:0 "
                          "(exercises launch/broadcast/shard/timing code where only one GPU is available)")
@@ -227,6 +228,44 @@ def main():
                    "peak": round(ceiling, 1), "unit": "images/s per GPU", "frac": round(per_gpu / ceiling, 4),
                    "simd_cycles_per_image_floor": round(floor_cyc, 1), "clock_ghz": CLK_HZ / 1e9,
                    "note": "the path is bound by integer VALU issue, not HBM: this is the meaningful ceiling (DESIGN.md 5)"}
+
+    # ---- secondary figures (single GPU only, outside the timed region of `value`)
+    if world == 1 and not a.no_extras:
+        # (a) PCIe-inclusive: the same batch from pageable HOST memory to int32 classes in host memory
+        host_imgs = imgs.cpu().numpy()
+        usec = C.c_float(0)
+        best = None
+        for _ in range(3):
+            t1 = time.perf_counter()
+            p = L.bnn_mi355x_inference_buffer(host_imgs.ctypes.data, a.batch, ncls, C.byref(usec), 0)
+            dt = time.perf_counter() - t1
+            if not p:
+                sys.exit(L.bnn_mi355x_last_error().decode())
+            L.free_results(p)
+            best = dt if best is None else min(best, dt)
+        out["pcie_inclusive"] = {"value": round(a.batch / best, 1), "unit": "images/s",
+                                 "note": "host buffer -> classes in host memory, H2D double-buffered against the stages (DESIGN.md 8)"}
+        del host_imgs
+        # (b) the same run with the int8 first layer on the integer pipe (v_dot4c) instead of the matrix pipe
+        if is_cnv:
+            size = L.bnn_mi355x_export_params(None, 0)
+            blob = np.zeros(size, np.uint8)
+            L.bnn_mi355x_export_params(blob.ctypes.data, size)
+            os.environ["BNN_MI355X_L0"] = "valu"
+            L.bnn_mi355x_import_params(blob.ctypes.data, size)
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+            out["first_layer_on_integer_pipe"] = {"value": round(5 * a.batch / (time.perf_counter() - t1), 1), "unit": "images/s",
+                                                  "note": "BNN_MI355X_L0=valu: no MFMA anywhere (DESIGN.md 5, 'Layer 0 on the matrix pipe')"}
+            del os.environ["BNN_MI355X_L0"]
+            L.bnn_mi355x_import_params(blob.ctypes.data, size)
+            step()
+            torch.cuda.synchronize()
 
     # ---- CPU baseline: the CPU restatement on this host's cores, bounded sample, same images
     if world == 1 and not a.no_cpu_baseline:
