@@ -41,7 +41,7 @@ typedef const uint32_t __attribute__((address_space(4))) *kptr32;
 typedef const uint64_t __attribute__((address_space(4))) *kptr64;
 
 constexpr int kBlock = 256;
-constexpr int kLfcFusedMax = 128;  // images: below this the block-per-image LFC kernel wins (tools/latency.py)
+constexpr int kLfcFusedMax = 4096;  // images: up to here the one-launch LFC kernel beats the six staged ones (tools/lfc_ab.py)
 
 // Block -> (work-item block, neuron group), XCD-aware.  The `groups` blocks that evaluate
 // different 32-neuron groups for the SAME 256 work items read the same input windows and write
@@ -793,49 +793,59 @@ __device__ __forceinline__ bool lfc_fires(const uint64_t (&w)[KW], int t, const 
   return m < t;
 }
 
+template <int IPB>
 __global__ __launch_bounds__(1024) void k_lfc_fused(const uint8_t *__restrict__ imgs, uint64_t *__restrict__ words,
                                                      int32_t *__restrict__ classes, const uint32_t *__restrict__ r0,
                                                      const uint32_t *__restrict__ r1, const uint32_t *__restrict__ r2,
-                                                     const uint32_t *__restrict__ r3, int number_class) {
-  __shared__ uint64_t act[2][16];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, img = blockIdx.x;
+                                                     const uint32_t *__restrict__ r3, int n_images, int number_class) {
+  __shared__ uint64_t act[2][IPB][16];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, img0 = blockIdx.x * IPB;
   // the layers are a dependent chain, their weight traffic need not be: the row of layer L+1 is
-  // requested before layer L is evaluated (two rows in flight: more would spill at 1024 threads)
+  // requested before layer L is evaluated (two rows in flight: more would spill at 1024 threads).
+  // A row, once in VGPRs, serves all IPB images of the block.
   uint64_t w0[13], w1[16], w2[16], w3[16];
   int t0, t1, t2, t3 = 0;
-  const uint8_t px = (t < 784) ? imgs[(size_t)img * 784 + t] : 0;
   lfc_load_row<13>(r0, t, w0, t0);
   // binarizeAndPack: bit i = (pixel i >= 128); pixels 784..831 are padding (0)
-  {
+#pragma unroll
+  for (int i = 0; i < IPB; i++) {
+    const int img = img0 + i < n_images ? img0 + i : n_images - 1;  // ragged tail: duplicate, store guarded
+    const uint8_t px = (t < 784) ? imgs[(size_t)img * 784 + t] : 0;
     const uint64_t word = __ballot(px >= 128);
-    if (lane == 0) act[0][wave] = word;  // waves 13..15 write zeros
+    if (lane == 0) act[0][i][wave] = word;  // waves 13..15 write zeros
   }
   lfc_load_row<16>(r1, t, w1, t1);
   __syncthreads();
-  {
-    const uint64_t word = __ballot(lfc_fires<13>(w0, t0, act[0]));
-    if (lane == 0) act[1][wave] = word;
+#pragma unroll
+  for (int i = 0; i < IPB; i++) {
+    const uint64_t word = __ballot(lfc_fires<13>(w0, t0, act[0][i]));
+    if (lane == 0) act[1][i][wave] = word;
   }
   lfc_load_row<16>(r2, t, w2, t2);
   __syncthreads();
-  {
-    const uint64_t word = __ballot(lfc_fires<16>(w1, t1, act[1]));
-    if (lane == 0) act[0][wave] = word;
+#pragma unroll
+  for (int i = 0; i < IPB; i++) {
+    const uint64_t word = __ballot(lfc_fires<16>(w1, t1, act[1][i]));
+    if (lane == 0) act[0][i][wave] = word;
   }
   if (wave == 0) lfc_load_row<16>(r3, lane, w3, t3);
   __syncthreads();
-  {
-    const uint64_t word = __ballot(lfc_fires<16>(w2, t2, act[0]));
-    if (lane == 0) act[1][wave] = word;
+#pragma unroll
+  for (int i = 0; i < IPB; i++) {
+    const uint64_t word = __ballot(lfc_fires<16>(w2, t2, act[0][i]));
+    if (lane == 0) act[1][i][wave] = word;
   }
   __syncthreads();
   if (wave == 0) {  // last layer: 64 neurons, one wave
-    const uint64_t word = __ballot(lfc_fires<16>(w3, t3, act[1]));
-    if (lane == 0) {
-      words[img] = word;
-      if (classes) {
-        const uint64_t w = word & (~0ull >> (64 - number_class));
-        classes[img] = w ? 63 - __builtin_clzll(w) : 0;
+#pragma unroll
+    for (int i = 0; i < IPB; i++) {
+      const uint64_t word = __ballot(lfc_fires<16>(w3, t3, act[1][i]));
+      if (lane == 0 && img0 + i < n_images) {
+        words[img0 + i] = word;
+        if (classes) {
+          const uint64_t w = word & (~0ull >> (64 - number_class));
+          classes[img0 + i] = w ? 63 - __builtin_clzll(w) : 0;
+        }
       }
     }
   }
@@ -1012,9 +1022,18 @@ hipError_t run_lfc(NetId net, const LfcLaunch &a) {
   uint64_t *A64 = reinterpret_cast<uint64_t *>(a.buf0), *B64 = reinterpret_cast<uint64_t *>(a.buf1);
   hipStream_t s = a.stream;
   if (net == NET_LFCW1A1 && n <= kLfcFusedMax && !a.events && a.last_stage >= kLfcStages - 1) {
-    // small batch: the one-launch, block-per-image form (no per-stage events: there are no stages)
-    hipLaunchKernelGGL(k_lfc_fused, dim3((unsigned)n), dim3(1024), 0, s, a.images, a.words, a.classes, a.rows[0], a.rows[1],
-                       a.rows[2], a.rows[3], a.number_class);
+    // small batch: the one-launch form, a block per group of IPB images (no per-stage events: there are no
+    // stages).  A block costs ~8 us + ~1.6 us per further image whatever the batch, so the group is the
+    // smallest that still fits the batch in one round of 256 blocks (profiles/r01_lfc_forms.txt).
+    const int ipb = n <= 256 ? 1 : n <= 512 ? 2 : n <= 1024 ? 4 : 8;
+    const dim3 g((unsigned)((n + ipb - 1) / ipb)), b(1024);
+#define BNN_FUSED(I) \
+  hipLaunchKernelGGL(k_lfc_fused<I>, g, b, 0, s, a.images, a.words, a.classes, a.rows[0], a.rows[1], a.rows[2], a.rows[3], (int)n, a.number_class)
+    if (ipb == 1) BNN_FUSED(1);
+    else if (ipb == 2) BNN_FUSED(2);
+    else if (ipb == 4) BNN_FUSED(4);
+    else BNN_FUSED(8);
+#undef BNN_FUSED
     return hipGetLastError();
   }
   BNN_MARK(a.events, 0, s);

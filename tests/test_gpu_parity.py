@@ -247,9 +247,10 @@ def test_device_api_crosses_the_chunk_boundary():
     assert (cls2 == cls[131072:]).all()
 
 
-@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 128, 129])
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 128, 129, 256, 257, 511, 512, 513, 1023, 1025, 2047, 4093, 4096, 4097])
 def test_lfc_small_batches_take_the_fused_kernel(n):
-    """<= 128 images: lfcW1A1 runs as one launch, one block per image (k_lfc_fused); 129 takes the staged path"""
+    """<= 4096 images: lfcW1A1 runs as one launch, a block per group of 1/2/4/8 images (k_lfc_fused<IPB>);
+    sizes either side of every policy edge, ragged last groups included; 4097 takes the staged path"""
     import torch
     net = gpu_net("lfcW1A1", "mnist")
     o = oracle("lfcW1A1", "mnist")
