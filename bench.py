@@ -54,12 +54,15 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PAIR_CYC, SLOT_CYC, N_SIMD, CLK_HZ = 6.6, 4.2, 1024, 2.38e9
 WORD_MACS = {"cnv": 905216, "lfc": 47104}          # 64-bit word-MACs per image, layers 1..
 PAIRS_PER_WORD = {"W1A1": 2, "W1A2": 2, "W2A2": 4}  # (logic op + v_bcnt) pairs per 64-bit word-MAC
+# measured pair rates (profiles/r01_microbench6/7): xor+bcnt and bitop3+bcnt 6.6; the W2A2 quad
+# (and, bcnt, bitop3 on the and's result, bcnt) 14.2 per 32 synapses = 7.1 per pair
+PAIR_CYC_OF = {"W1A1": PAIR_CYC, "W1A2": PAIR_CYC, "W2A2": 7.1}
 
 
 def issue_floor_cycles(network):
     """SIMD-cycles per image if the integer pipe issued nothing but the unavoidable instructions"""
     kind, prec = network[:3], network[3:]
-    cyc = WORD_MACS[kind] * PAIRS_PER_WORD[prec] * PAIR_CYC
+    cyc = WORD_MACS[kind] * PAIRS_PER_WORD[prec] * PAIR_CYC_OF[prec]
     if kind == "cnv":
         # layer 0 runs on the matrix pipe (v_mfma_i32_32x32x32_i8); what stays on the integer pipe is the
         # tap gather + quantise (~105 instructions per pixel-lane) and one v_alignbit per neuron (64) + merges
