@@ -17,7 +17,7 @@ EXT = ["bnn_mi355x_network", "bnn_mi355x_image_bytes", "bnn_mi355x_last_error", 
        "bnn_mi355x_inference_buffer", "bnn_mi355x_inference_raw", "bnn_mi355x_inference_device",
        "bnn_mi355x_reserve", "bnn_mi355x_set_fault_seed", "bnn_mi355x_last_faults", "bnn_mi355x_plan_faults",
        "bnn_mi355x_pack_params_faulty", "bnn_mi355x_debug_stage_output", "bnn_mi355x_profile",
-       "bnn_mi355x_profile_read", "bnn_mi355x_stage_name"]
+       "bnn_mi355x_profile_read", "bnn_mi355x_stage_name", "bnn_mi355x_thumbnail_size", "bnn_mi355x_images_to_cifar"]
 
 
 def lib_path(network, runtime="python_sw", lib_dir=None):
@@ -69,6 +69,8 @@ def declare_extensions(L):
     L.bnn_mi355x_profile_read.argtypes = [fp, C.c_int, ip]
     L.bnn_mi355x_stage_name.argtypes = [C.c_int]
     L.bnn_mi355x_stage_name.restype = C.c_char_p
+    L.bnn_mi355x_thumbnail_size.argtypes = [C.c_int, C.c_int, ip, ip]
+    L.bnn_mi355x_images_to_cifar.argtypes = [C.POINTER(C.c_void_p), ip, ip, ip, C.POINTER(C.c_long), C.c_int, C.c_void_p]
 
 
 _cache = {}

@@ -238,10 +238,50 @@ class CnvClassifier:
         for ch in range(3):
             fp.write(px[:, :, ch].flatten().tobytes())
 
+    def images_to_cifar(self, imgs):
+        """CIFAR-10 records (uint8 array [n, 3073]) of a list of PIL images (or decoded pictures as
+        uint8 arrays [H, W, 3] / [H, W], which skips the PIL -> numpy copy), the resampling done on
+        the GPU (``bnn_mi355x_images_to_cifar``): same bytes as :meth:`image_to_cifar` writes, but
+        the caller's images are left as they are (the reference's ``thumbnail`` shrinks them in
+        place).  Modes other than RGB and L (alpha, palette, ...) take the PIL route on the host."""
+        import io
+        recs = np.empty((len(imgs), 3073), dtype=np.uint8)
+        arrays, where = [], []
+        # a library with only the reference's six symbols (the reference's own .so) has no such entry point
+        on_device = hasattr(self.bnn.interface, "bnn_mi355x_images_to_cifar")
+        for i, img in enumerate(imgs):
+            if isinstance(img, np.ndarray):  # a decoded picture: uint8 [H, W, 3] (RGB) or [H, W] (L)
+                if img.dtype != np.uint8 or not (img.ndim == 2 or (img.ndim == 3 and img.shape[2] == 3)):
+                    raise ValueError("pictures given as arrays must be uint8 [H, W, 3] or [H, W]")
+                if not on_device:
+                    img = Image.fromarray(img)
+                else:
+                    arrays.append(np.ascontiguousarray(img))
+                    where.append(i)
+                    continue
+            if on_device and img.mode in ("RGB", "L"):
+                arrays.append(np.ascontiguousarray(np.asarray(img)))
+                where.append(i)
+            else:
+                buf = io.BytesIO()
+                self.image_to_cifar(img.copy(), buf)
+                recs[i] = np.frombuffer(buf.getvalue(), dtype=np.uint8)
+        n = len(arrays)
+        if n:
+            ptrs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrays])
+            ws = (ctypes.c_int * n)(*[a.shape[1] for a in arrays])
+            hs = (ctypes.c_int * n)(*[a.shape[0] for a in arrays])
+            bs = (ctypes.c_int * n)(*[1 if a.ndim == 2 else a.shape[2] for a in arrays])
+            out = np.empty((n, 3073), dtype=np.uint8)
+            lib = self.bnn.interface
+            if lib.bnn_mi355x_images_to_cifar(ptrs, ws, hs, bs, None, n, out.ctypes.data) != 0:
+                raise RuntimeError(lib.bnn_mi355x_last_error().decode())
+            recs[where] = out
+        return recs
+
     def _with_tmp(self, imgs, fn):
         with tempfile.NamedTemporaryFile() as tmp:
-            for img in imgs:
-                self.image_to_cifar(img, tmp)
+            tmp.write(self.images_to_cifar(list(imgs)).tobytes())
             tmp.flush()
             result = fn(tmp.name)
         self.usecPerImage = self.bnn.usecPerImage

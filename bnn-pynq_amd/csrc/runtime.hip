@@ -26,6 +26,8 @@
 #include "../../include/bnn_mi355x.h"
 #include "faults.h"
 #include "kernels.h"
+#include "preprocess.h"
+#include "resample.h"
 #include "packed_params.h"
 #include "topology.h"
 
@@ -65,6 +67,11 @@ struct Runtime {
   hipStream_t stream = nullptr, copy_stream = nullptr;
   hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
   std::vector<hipEvent_t> time_events;
+  // picture -> CIFAR record (bnn_mi355x_images_to_cifar): source picture, horizontal-pass output,
+  // coefficient tables, records
+  size_t pp_src_cap = 0, pp_tmp_cap = 0, pp_coef_cap = 0, pp_rec_cap = 0;
+  uint8_t *d_pp_src = nullptr, *d_pp_tmp = nullptr, *d_pp_rec = nullptr;
+  int32_t *d_pp_coef = nullptr;
   // optional per-stage profiling (bnn_mi355x_profile): one event set per enqueued chunk
   bool profiling = false;
   std::vector<std::vector<hipEvent_t>> prof_sets;
@@ -122,7 +129,7 @@ int upload_blob() {
 
 void free_workspace() {
   Runtime &r = rt();
-  if (r.cap == 0 && r.stage_cap == 0 && r.res_cap == 0) return;
+  if (r.cap == 0 && r.stage_cap == 0 && r.res_cap == 0 && !r.d_pp_src && !r.d_pp_rec) return;
   if (r.device >= 0) (void)hipSetDevice(r.device);
   (void)hipDeviceSynchronize();
   (void)hipFree(r.buf0); (void)hipFree(r.buf1); (void)hipFree(r.d_images[0]); (void)hipFree(r.d_images[1]);
@@ -131,6 +138,24 @@ void free_workspace() {
   r.d_scores = nullptr; r.d_classes = nullptr; r.d_words = nullptr;
   r.cap = r.stage_cap = 0;
   r.res_cap = 0;
+  (void)hipFree(r.d_pp_src); (void)hipFree(r.d_pp_tmp); (void)hipFree(r.d_pp_rec); (void)hipFree(r.d_pp_coef);
+  r.d_pp_src = r.d_pp_tmp = r.d_pp_rec = nullptr;
+  r.d_pp_coef = nullptr;
+  r.pp_src_cap = r.pp_tmp_cap = r.pp_coef_cap = r.pp_rec_cap = 0;
+}
+
+// grow-only device buffer (contents are not preserved)
+template <typename T>
+int grow(T *&ptr, size_t &cap, size_t need) {
+  if (need <= cap) return 0;
+  HIP_OK(hipStreamSynchronize(rt().stream));
+  (void)hipFree(ptr);
+  ptr = nullptr;
+  cap = 0;
+  const size_t n = need + need / 4 + 256;
+  HIP_OK(hipMalloc(reinterpret_cast<void **>(&ptr), n * sizeof(T)));
+  cap = n;
+  return 0;
 }
 
 // activation workspace for `n` images per pass (at most kMaxChunk)
@@ -601,6 +626,72 @@ int bnn_mi355x_last_faults(int *records, int cap_records) {
     for (int j = 0; j < 8; j++) records[i * 8 + j] = v[j];
   }
   return n;
+}
+
+int bnn_mi355x_thumbnail_size(int width, int height, int *out_w, int *out_h) {
+  int ow = width, oh = height;
+  const bool resized = width > 0 && height > 0 && thumbnail_size(width, height, 32, &ow, &oh);
+  if (out_w) *out_w = ow;
+  if (out_h) *out_h = oh;
+  return resized ? 1 : 0;
+}
+
+int bnn_mi355x_images_to_cifar(const uint8_t *const *pixels, const int *widths, const int *heights, const int *bands,
+                               const long *row_strides, int n_images, uint8_t *records) {
+  Runtime &r = rt();
+  if (!r.spec.is_cnv) return fail("images_to_cifar: CIFAR-10 records are the input of the CNV networks only");
+  if (n_images < 0 || (n_images > 0 && (!pixels || !widths || !heights || !bands || !records)))
+    return fail("images_to_cifar: bad arguments");
+  if (n_images == 0) return 0;
+  if (bind_device()) return -1;
+  if (grow(r.d_pp_rec, r.pp_rec_cap, (size_t)n_images * 3073)) return -1;
+  // host copies of the coefficient tables must outlive their (asynchronous) upload: kept until the next sync
+  std::vector<std::vector<int32_t>> keep;
+  int last_w = -1, last_h = -1;
+  size_t off_bh = 0, off_kv = 0, off_bv = 0;
+  int ksize_h = 0, ksize_v = 0, ow = 0, oh = 0;
+  for (int i = 0; i < n_images; i++) {
+    const int w = widths[i], h = heights[i], nb = bands[i];
+    if (!pixels[i] || w < 1 || h < 1 || w > 65535 || h > 65535 || (nb != 1 && nb != 3))
+      return fail("images_to_cifar: image " + std::to_string(i) + ": need 1..65535 x 1..65535 pixels of 1 (L) or 3 (RGB) bytes");
+    const size_t row_bytes = (size_t)w * nb;
+    const long stride = row_strides ? row_strides[i] : (long)row_bytes;
+    if (stride < (long)row_bytes) return fail("images_to_cifar: row stride shorter than a row");
+    if (w != last_w || h != last_h) {
+      ow = w; oh = h;
+      (void)thumbnail_size(w, h, 32, &ow, &oh);
+      std::vector<int32_t> kh, bh, kv, bv, all;
+      ksize_h = lanczos_coeffs(w, ow, kh, bh);
+      ksize_v = lanczos_coeffs(h, oh, kv, bv);
+      off_bh = kh.size(); off_kv = off_bh + bh.size(); off_bv = off_kv + kv.size();
+      all.reserve(off_bv + bv.size());
+      all.insert(all.end(), kh.begin(), kh.end()); all.insert(all.end(), bh.begin(), bh.end());
+      all.insert(all.end(), kv.begin(), kv.end()); all.insert(all.end(), bv.begin(), bv.end());
+      if (grow(r.d_pp_coef, r.pp_coef_cap, all.size())) return -1;
+      if (keep.size() >= 16) { HIP_OK(hipStreamSynchronize(r.stream)); keep.clear(); }
+      keep.push_back(std::move(all));
+      HIP_OK(hipMemcpyAsync(r.d_pp_coef, keep.back().data(), keep.back().size() * sizeof(int32_t), hipMemcpyHostToDevice, r.stream));
+      last_w = w; last_h = h;
+    }
+    if (grow(r.d_pp_src, r.pp_src_cap, row_bytes * h) || grow(r.d_pp_tmp, r.pp_tmp_cap, (size_t)(h > w ? h : w) * 32 * 3 + 3072)) return -1;
+    if ((size_t)stride == row_bytes)
+      HIP_OK(hipMemcpyAsync(r.d_pp_src, pixels[i], row_bytes * h, hipMemcpyHostToDevice, r.stream));
+    else
+      HIP_OK(hipMemcpy2DAsync(r.d_pp_src, row_bytes, pixels[i], (size_t)stride, row_bytes, (size_t)h, hipMemcpyHostToDevice, r.stream));
+    ResampleJob j{};
+    j.src = r.d_pp_src; j.w = w; j.h = h; j.bands = nb; j.stride = (long)row_bytes;
+    j.out_w = ow; j.out_h = oh;
+    j.vertical_first = vertical_pass_first(w, h, oh);
+    j.kh = r.d_pp_coef; j.bh = r.d_pp_coef + off_bh; j.ksize_h = ksize_h;
+    j.kv = r.d_pp_coef + off_kv; j.bv = r.d_pp_coef + off_bv; j.ksize_v = ksize_v;
+    j.tmp = r.d_pp_tmp;
+    j.record = r.d_pp_rec + (size_t)i * 3073;
+    const hipError_t e = launch_image_to_cifar(j, r.stream);
+    if (e != hipSuccess) return fail(std::string("images_to_cifar: kernel launch: ") + hipGetErrorString(e));
+  }
+  HIP_OK(hipMemcpyAsync(records, r.d_pp_rec, (size_t)n_images * 3073, hipMemcpyDeviceToHost, r.stream));
+  HIP_OK(hipStreamSynchronize(r.stream));
+  return 0;
 }
 
 int bnn_mi355x_profile(int enable) {

@@ -132,6 +132,22 @@ int bnn_mi355x_plan_faults(unsigned long long seed, int num_images, unsigned int
                            const int *target_layers, unsigned int num_targets, int *records, int cap_records);
 size_t bnn_mi355x_pack_params_faulty(const char *path, const int *records, int n_faults, void *dst, size_t cap);
 
+/* The step before the path: CnvClassifier.image_to_cifar (bnn/bnn.py:226-242) on the
+ * device.  The reference shrinks a picture with PIL's Image.thumbnail((32, 32), ANTIALIAS) -- Lanczos-3,
+ * Pillow's 8-bit fixed-point two-pass resampler -- pastes it centred on a white 32x32 canvas and writes
+ * a CIFAR-10 record: label byte 1, then the R, G, B planes (3073 bytes).  These two entry points do the
+ * same for decoded pictures in host memory; the records are bit-identical to Pillow's
+ * (tests/test_image_to_cifar.py).  CNV libraries only.
+ *   pixels[i]: heights[i] rows of widths[i] pixels of bands[i] bytes (1 = mode "L", 3 = mode "RGB"),
+ *              rows row_strides[i] bytes apart (row_strides NULL: packed rows);
+ *   records:   n_images x 3073 bytes, host.
+ * Pictures of other modes (alpha, palette) stay with PIL on the host, like in the reference.
+ * thumbnail_size: the size Image.thumbnail((32, 32)) gives a width x height picture; returns 1 when
+ * the picture is resampled, 0 when it already fits (out = in). */
+int bnn_mi355x_thumbnail_size(int width, int height, int *out_w, int *out_h);
+int bnn_mi355x_images_to_cifar(const uint8_t *const *pixels, const int *widths, const int *heights, const int *bands,
+                               const long *row_strides, int n_images, uint8_t *records);
+
 /* Test hook: run the stages 0..stage on n host images (n <= 32768) and copy that stage's output,
  * exactly as it sits in HBM (bit-packed activation layout), to dst.  CNV: stage L =
  * layer L (0..7, after the max-pool where there is one); LFC: stage 0 = binarised input, stage
