@@ -41,7 +41,7 @@ typedef const uint32_t __attribute__((address_space(4))) *kptr32;
 typedef const uint64_t __attribute__((address_space(4))) *kptr64;
 
 constexpr int kBlock = 256;
-constexpr int kLfcFusedMax = 4096;  // images: up to here the one-launch LFC kernel beats the six staged ones (tools/lfc_ab.py)
+constexpr int kLfcFusedMax = 4096;  // images: up to here the one-launch LFC kernel beats the six staged ones (tools/batch_sweep.py)
 
 // Block -> (work-item block, neuron group), XCD-aware.  The `groups` blocks that evaluate
 // different 32-neuron groups for the SAME 256 work items read the same input windows and write
@@ -68,15 +68,26 @@ __device__ __forceinline__ int pc64(uint64_t x) { return __builtin_popcountll(x)
 // ---------------------------------------------------------------------------
 // 1-bit maps:  [pixel][Cout/32] dwords, bit c of dword g = channel 32g+c fired (+1).
 // 2-bit maps:  [pixel][Cout/64][plane] u64, plane 0 = sign (1 <=> -1), plane 1 = non-zero.
-template <bool OUT2>
+// NPB = neurons per block: 32 (a dword of the word, the throughput form) or 8 (a byte of it, the
+// small-batch form: four times as many, four times shorter blocks); g counts groups of NPB neurons.
+template <bool OUT2, int NPB = 32>
 __device__ __forceinline__ void store_bits(uint32_t *__restrict__ out, size_t pix, int groups, int g,
                                            uint32_t b0, uint32_t b1) {
+  constexpr int PER64 = 64 / NPB;  // groups per 64 channels
   if constexpr (!OUT2) {
-    out[pix * groups + g] = b0;
+    if constexpr (NPB == 32) out[pix * groups + g] = b0;
+    else reinterpret_cast<uint8_t *>(out)[pix * groups + g] = (uint8_t)b0;
   } else {
-    const size_t w64 = pix * (groups >> 1) + (g >> 1);
-    out[(w64 * 2 + 0) * 2 + (g & 1)] = b0;
-    out[(w64 * 2 + 1) * 2 + (g & 1)] = b1;
+    const size_t w64 = pix * (groups / PER64) + g / PER64;
+    const int sub = g % PER64;
+    if constexpr (NPB == 32) {
+      out[(w64 * 2 + 0) * 2 + sub] = b0;
+      out[(w64 * 2 + 1) * 2 + sub] = b1;
+    } else {
+      uint8_t *o8 = reinterpret_cast<uint8_t *>(out);
+      o8[(w64 * 2 + 0) * 8 + sub] = (uint8_t)b0;
+      o8[(w64 * 2 + 1) * 8 + sub] = (uint8_t)b1;
+    }
   }
 }
 
@@ -544,7 +555,7 @@ __device__ __forceinline__ void finish_bits(uint32_t &b0, uint32_t &b1) {
 // 3x3 valid conv, one lane = a 2x2 quad of output pixels (4x4 window in VGPRs), optional pool.
 // Replaces ConvolutionInputGenerator + Matrix_Vector_Activate_Batch + ThresholdsActivation
 // (+ StreamingMaxPool_Precision_Batch) for CNV layers 1..3 of the A2 networks.
-template <int ARITH, int CW, int ID, bool POOL, bool OUT2>
+template <int ARITH, int CW, int ID, bool POOL, bool OUT2, int NPB = 32>
 __global__ __launch_bounds__(kBlock) void k_quad(const uint64_t *__restrict__ in, uint32_t *__restrict__ out,
                                                   const uint32_t *__restrict__ rows, int n_items, int groups, int gpb) {
   constexpr int OD = ID - 2, QD = OD / 2, NQ = QD * QD, PL = planes_in<ARITH>(), WPL = wplanes<ARITH>();
@@ -585,9 +596,9 @@ __global__ __launch_bounds__(kBlock) void k_quad(const uint64_t *__restrict__ in
               nn[dy][dx] -= __builtin_popcount(wz[dy + ky][dx + kx][k][0]) + __builtin_popcount(wz[dy + ky][dx + kx][k][1]);
   }
   for (int cg = bm.cg * gpb, cg_end = cg + gpb; cg < cg_end; cg++) {  // see k_conv0
-    kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)cg * 32 * ROW_DW);
+    kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)cg * NPB * ROW_DW);
     uint32_t b0[4] = {0, 0, 0, 0}, b1[4] = {0, 0, 0, 0};
-    for (int c = 31; c >= 0; c--) {
+    for (int c = NPB - 1; c >= 0; c--) {
       kptr32 r = w + c * ROW_DW;
       const int t0 = (int)r[0], t1 = (int)r[1];
       const int c0 = (ARITH == AR_XNOR) ? -t0 : t0, dt = (ARITH == AR_XNOR) ? (t0 - t1) : (t1 - t0);
@@ -616,13 +627,13 @@ __global__ __launch_bounds__(kBlock) void k_quad(const uint64_t *__restrict__ in
     }
     if constexpr (POOL) {
       finish_bits<OUT2>(b0[0], b1[0]);
-      store_bits<OUT2>(out, (size_t)item, groups, cg, b0[0], b1[0]);
+      store_bits<OUT2, NPB>(out, (size_t)item, groups, cg, b0[0], b1[0]);
     } else {
   #pragma unroll
       for (int i = 0; i < 4; i++) {
         const size_t pix = (size_t)img * OD * OD + (size_t)(2 * qy + (i >> 1)) * OD + 2 * qx + (i & 1);
         finish_bits<OUT2>(b0[i], b1[i]);
-        store_bits<OUT2>(out, pix, groups, cg, b0[i], b1[i]);
+        store_bits<OUT2, NPB>(out, pix, groups, cg, b0[i], b1[i]);
       }
     }
   }
@@ -630,7 +641,7 @@ __global__ __launch_bounds__(kBlock) void k_quad(const uint64_t *__restrict__ in
 
 // Generic "KW words in, thresholded bits out": one lane = one vector (FC layers, CNV layer 5,
 // and with SINGLE the 3x3 window gather of CNV layer 4).  Two neurons per iteration.
-template <int ARITH, int KW, bool OUT2, bool SINGLE, int CW, int ID>
+template <int ARITH, int KW, bool OUT2, bool SINGLE, int CW, int ID, int NPB = 32>
 __global__ __launch_bounds__(kBlock) void k_vec(const uint64_t *__restrict__ in, uint32_t *__restrict__ out,
                                                  const uint32_t *__restrict__ rows, int n_items, int groups, int gpb) {
   constexpr int PL = planes_in<ARITH>(), WPL = wplanes<ARITH>();
@@ -670,9 +681,9 @@ __global__ __launch_bounds__(kBlock) void k_vec(const uint64_t *__restrict__ in,
     for (int k = 0; k < KW; k++) nn -= __builtin_popcount(az[k][0]) + __builtin_popcount(az[k][1]);
   }
   for (int cg = bm.cg * gpb, cg_end = cg + gpb; cg < cg_end; cg++) {  // see k_conv0
-    kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)cg * 32 * ROW_DW);
+    kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)cg * NPB * ROW_DW);
     uint32_t b0 = 0, b1 = 0;
-    for (int c = 31; c >= 0; c -= 2) {
+    for (int c = NPB - 1; c >= 0; c -= 2) {
       kptr32 rA = w + c * ROW_DW, rB = rA - ROW_DW;
       int mA = 0, zA = 0, mB = 0, zB = 0;
   #pragma unroll
@@ -692,7 +703,7 @@ __global__ __launch_bounds__(kBlock) void k_vec(const uint64_t *__restrict__ in,
       }
     }
     finish_bits<OUT2>(b0, b1);
-    store_bits<OUT2>(out, (size_t)item, groups, cg, b0, b1);
+    store_bits<OUT2, NPB>(out, (size_t)item, groups, cg, b0, b1);
   }
 }
 
@@ -881,6 +892,14 @@ inline dim3 grid_for(long long items, int groups) {  // matches map_block()
   do {                                                                        \
     if ((grid).x > 0) hipLaunchKernelGGL(kern, grid, dim3(kBlock), 0, stream, __VA_ARGS__); \
   } while (0)
+// one thresholded stage over `items` work items and `groups32` groups of 32 neurons: the 8-neuron
+// form for small batches (narrow_for), else the 32-neuron form with gpb_for() groups per block
+#define BNN_STAGE(kern32, kern8, items, groups32, in, out, rows)                                                                   \
+  do {                                                                                                                             \
+    const long long it_ = (items);                                                                                                 \
+    if (narrow_for(it_, (groups32))) BNN_LAUNCH(kern8, grid_for(it_, (groups32) * 4), s, in, out, rows, (int)it_, (groups32) * 4, 1); \
+    else BNN_LAUNCH(kern32, grid_for(it_, (groups32) / gpb_for(it_, (groups32))), s, in, out, rows, (int)it_, (groups32), gpb_for(it_, (groups32))); \
+  } while (0)
 // stage boundary: with profiling on, an event separates consecutive stages
 #define BNN_MARK(ev, i, stream)                          \
   do {                                                   \
@@ -902,70 +921,35 @@ void run_cnv_t(const CnvLaunch &a) {
   }
   BNN_MARK(a.events, 1, s);
   if constexpr (ARITH == AR_XNOR && !OUT2) {
-    if (a.last_stage >= 1) {
-      if (narrow_for(n * 196, 2))
-        BNN_LAUNCH((k_quad_x<1, 30, true, 8>), grid_for(n * 196, 8), s, A64, B, a.rows[1], (int)(n * 196), 8, 1);
-      else
-        BNN_LAUNCH((k_quad_x<1, 30, true>), grid_for(n * 196, 2 / gpb_for(n * 196, 2)), s, A64, B, a.rows[1], (int)(n * 196), 2, gpb_for(n * 196, 2));
-    }
+    if (a.last_stage >= 1) BNN_STAGE((k_quad_x<1, 30, true>), (k_quad_x<1, 30, true, 8>), n * 196, 2, A64, B, a.rows[1]);
     BNN_MARK(a.events, 2, s);
-    if (a.last_stage >= 2) {
-      if (narrow_for(n * 36, 4))
-        BNN_LAUNCH((k_quad_x<1, 14, false, 8>), grid_for(n * 36, 16), s, B64, A, a.rows[2], (int)(n * 36), 16, 1);
-      else
-        BNN_LAUNCH((k_quad_x<1, 14, false>), grid_for(n * 36, 4 / gpb_for(n * 36, 4)), s, B64, A, a.rows[2], (int)(n * 36), 4, gpb_for(n * 36, 4));
-    }
+    if (a.last_stage >= 2) BNN_STAGE((k_quad_x<1, 14, false>), (k_quad_x<1, 14, false, 8>), n * 36, 4, B64, A, a.rows[2]);
     BNN_MARK(a.events, 3, s);
-    if (a.last_stage >= 3) {
-      if (narrow_for(n * 25, 4))
-        BNN_LAUNCH((k_quad_x<2, 12, true, 8>), grid_for(n * 25, 16), s, A64, B, a.rows[3], (int)(n * 25), 16, 1);
-      else
-        BNN_LAUNCH((k_quad_x<2, 12, true>), grid_for(n * 25, 4 / gpb_for(n * 25, 4)), s, A64, B, a.rows[3], (int)(n * 25), 4, gpb_for(n * 25, 4));
-    }
+    if (a.last_stage >= 3) BNN_STAGE((k_quad_x<2, 12, true>), (k_quad_x<2, 12, true, 8>), n * 25, 4, A64, B, a.rows[3]);
     BNN_MARK(a.events, 4, s);
-    if (a.last_stage >= 4) {
-      if (narrow_for(n * 9, 8))
-        BNN_LAUNCH((k_vec_x<18, true, 2, 5, 8>), grid_for(n * 9, 32), s, B64, A, a.rows[4], (int)(n * 9), 32, 1);
-      else
-        BNN_LAUNCH((k_vec_x<18, true, 2, 5>), grid_for(n * 9, 8 / gpb_for(n * 9, 8)), s, B64, A, a.rows[4], (int)(n * 9), 8, gpb_for(n * 9, 8));
-    }
+    if (a.last_stage >= 4) BNN_STAGE((k_vec_x<18, true, 2, 5>), (k_vec_x<18, true, 2, 5, 8>), n * 9, 8, B64, A, a.rows[4]);
     BNN_MARK(a.events, 5, s);
-    if (a.last_stage >= 5) {
-      if (narrow_for(n, 8))
-        BNN_LAUNCH((k_vec_x<36, false, 1, 1, 8>), grid_for(n, 32), s, A64, B, a.rows[5], (int)(n), 32, 1);
-      else
-        BNN_LAUNCH((k_vec_x<36, false, 1, 1>), grid_for(n, 8 / gpb_for(n, 8)), s, A64, B, a.rows[5], (int)(n), 8, gpb_for(n, 8));
-    }
+    if (a.last_stage >= 5) BNN_STAGE((k_vec_x<36, false, 1, 1>), (k_vec_x<36, false, 1, 1, 8>), n, 8, A64, B, a.rows[5]);
     BNN_MARK(a.events, 6, s);
-    if (a.last_stage >= 6) {
-      if (narrow_for(n, 16))
-        BNN_LAUNCH((k_vec_x<4, false, 1, 1, 8>), grid_for(n, 64), s, B64, A, a.rows[6], (int)(n), 64, 1);
-      else
-        BNN_LAUNCH((k_vec_x<4, false, 1, 1>), grid_for(n, 16 / gpb_for(n, 16)), s, B64, A, a.rows[6], (int)(n), 16, gpb_for(n, 16));
-    }
+    if (a.last_stage >= 6) BNN_STAGE((k_vec_x<4, false, 1, 1>), (k_vec_x<4, false, 1, 1, 8>), n, 16, B64, A, a.rows[6]);
     BNN_MARK(a.events, 7, s);
-    if (a.last_stage >= 7) {
-      if (narrow_for(n, 16))
-        BNN_LAUNCH((k_vec_x<8, false, 1, 1, 8>), grid_for(n, 64), s, A64, B, a.rows[7], (int)(n), 64, 1);
-      else
-        BNN_LAUNCH((k_vec_x<8, false, 1, 1>), grid_for(n, 16 / gpb_for(n, 16)), s, A64, B, a.rows[7], (int)(n), 16, gpb_for(n, 16));
-    }
+    if (a.last_stage >= 7) BNN_STAGE((k_vec_x<8, false, 1, 1>), (k_vec_x<8, false, 1, 1, 8>), n, 16, A64, B, a.rows[7]);
     BNN_MARK(a.events, 8, s);
   } else {
-  if (a.last_stage >= 1) BNN_LAUNCH((k_quad<ARITH, 1, 30, true, OUT2>), grid_for(n * 196, 2 / gpb_for(n * 196, 2)), s, A64, B, a.rows[1], (int)(n * 196), 2, gpb_for(n * 196, 2));
-  BNN_MARK(a.events, 2, s);
-  if (a.last_stage >= 2) BNN_LAUNCH((k_quad<ARITH, 1, 14, false, OUT2>), grid_for(n * 36, 4 / gpb_for(n * 36, 4)), s, B64, A, a.rows[2], (int)(n * 36), 4, gpb_for(n * 36, 4));
-  BNN_MARK(a.events, 3, s);
-  if (a.last_stage >= 3) BNN_LAUNCH((k_quad<ARITH, 2, 12, true, OUT2>), grid_for(n * 25, 4 / gpb_for(n * 25, 4)), s, A64, B, a.rows[3], (int)(n * 25), 4, gpb_for(n * 25, 4));
-  BNN_MARK(a.events, 4, s);
-  if (a.last_stage >= 4) BNN_LAUNCH((k_vec<ARITH, 18, OUT2, true, 2, 5>), grid_for(n * 9, 8 / gpb_for(n * 9, 8)), s, B64, A, a.rows[4], (int)(n * 9), 8, gpb_for(n * 9, 8));
-  BNN_MARK(a.events, 5, s);
-  if (a.last_stage >= 5) BNN_LAUNCH((k_vec<ARITH, 36, OUT2, false, 1, 1>), grid_for(n, 8 / gpb_for(n, 8)), s, A64, B, a.rows[5], (int)n, 8, gpb_for(n, 8));
-  BNN_MARK(a.events, 6, s);
-  if (a.last_stage >= 6) BNN_LAUNCH((k_vec<ARITH, 4, OUT2, false, 1, 1>), grid_for(n, 16 / gpb_for(n, 16)), s, B64, A, a.rows[6], (int)n, 16, gpb_for(n, 16));
-  BNN_MARK(a.events, 7, s);
-  if (a.last_stage >= 7) BNN_LAUNCH((k_vec<ARITH, 8, OUT2, false, 1, 1>), grid_for(n, 16 / gpb_for(n, 16)), s, A64, B, a.rows[7], (int)n, 16, gpb_for(n, 16));
-  BNN_MARK(a.events, 8, s);
+    if (a.last_stage >= 1) BNN_STAGE((k_quad<ARITH, 1, 30, true, OUT2>), (k_quad<ARITH, 1, 30, true, OUT2, 8>), n * 196, 2, A64, B, a.rows[1]);
+    BNN_MARK(a.events, 2, s);
+    if (a.last_stage >= 2) BNN_STAGE((k_quad<ARITH, 1, 14, false, OUT2>), (k_quad<ARITH, 1, 14, false, OUT2, 8>), n * 36, 4, B64, A, a.rows[2]);
+    BNN_MARK(a.events, 3, s);
+    if (a.last_stage >= 3) BNN_STAGE((k_quad<ARITH, 2, 12, true, OUT2>), (k_quad<ARITH, 2, 12, true, OUT2, 8>), n * 25, 4, A64, B, a.rows[3]);
+    BNN_MARK(a.events, 4, s);
+    if (a.last_stage >= 4) BNN_STAGE((k_vec<ARITH, 18, OUT2, true, 2, 5>), (k_vec<ARITH, 18, OUT2, true, 2, 5, 8>), n * 9, 8, B64, A, a.rows[4]);
+    BNN_MARK(a.events, 5, s);
+    if (a.last_stage >= 5) BNN_STAGE((k_vec<ARITH, 36, OUT2, false, 1, 1>), (k_vec<ARITH, 36, OUT2, false, 1, 1, 8>), n, 8, A64, B, a.rows[5]);
+    BNN_MARK(a.events, 6, s);
+    if (a.last_stage >= 6) BNN_STAGE((k_vec<ARITH, 4, OUT2, false, 1, 1>), (k_vec<ARITH, 4, OUT2, false, 1, 1, 8>), n, 16, B64, A, a.rows[6]);
+    BNN_MARK(a.events, 7, s);
+    if (a.last_stage >= 7) BNN_STAGE((k_vec<ARITH, 8, OUT2, false, 1, 1>), (k_vec<ARITH, 8, OUT2, false, 1, 1, 8>), n, 16, A64, B, a.rows[7]);
+    BNN_MARK(a.events, 8, s);
   }
   if (a.last_stage >= 8) BNN_LAUNCH((k_fclast<ARITH, 8>), grid_for(n, 1), s, B64, a.scores, a.classes, a.rows[8], (int)n, a.number_class);
   BNN_MARK(a.events, 9, s);
@@ -1039,23 +1023,24 @@ hipError_t run_lfc(NetId net, const LfcLaunch &a) {
   BNN_MARK(a.events, 0, s);
   if (a.last_stage >= 0) BNN_LAUNCH(k_lfc_binarize, grid_for(n * 13, 1), s, a.images, A64, (int)(n * 13));
   BNN_MARK(a.events, 1, s);
+  uint32_t *W32 = reinterpret_cast<uint32_t *>(a.words);
   if (net == NET_LFCW1A1) {
-    if (a.last_stage >= 1) BNN_LAUNCH((k_vec_x<13, false, 1, 1>), grid_for(n, 32 / gpb_for(n, 32)), s, A64, B, a.rows[0], (int)n, 32, gpb_for(n, 32));
+    if (a.last_stage >= 1) BNN_STAGE((k_vec_x<13, false, 1, 1>), (k_vec_x<13, false, 1, 1, 8>), n, 32, A64, B, a.rows[0]);
     BNN_MARK(a.events, 2, s);
-    if (a.last_stage >= 2) BNN_LAUNCH((k_vec_x<16, false, 1, 1>), grid_for(n, 32 / gpb_for(n, 32)), s, B64, A, a.rows[1], (int)n, 32, gpb_for(n, 32));
+    if (a.last_stage >= 2) BNN_STAGE((k_vec_x<16, false, 1, 1>), (k_vec_x<16, false, 1, 1, 8>), n, 32, B64, A, a.rows[1]);
     BNN_MARK(a.events, 3, s);
-    if (a.last_stage >= 3) BNN_LAUNCH((k_vec_x<16, false, 1, 1>), grid_for(n, 32 / gpb_for(n, 32)), s, A64, B, a.rows[2], (int)n, 32, gpb_for(n, 32));
+    if (a.last_stage >= 3) BNN_STAGE((k_vec_x<16, false, 1, 1>), (k_vec_x<16, false, 1, 1, 8>), n, 32, A64, B, a.rows[2]);
     BNN_MARK(a.events, 4, s);
-    if (a.last_stage >= 4) BNN_LAUNCH((k_vec_x<16, false, 1, 1>), grid_for(n, 2 / gpb_for(n, 2)), s, B64, reinterpret_cast<uint32_t *>(a.words), a.rows[3], (int)n, 2, gpb_for(n, 2));
+    if (a.last_stage >= 4) BNN_STAGE((k_vec_x<16, false, 1, 1>), (k_vec_x<16, false, 1, 1, 8>), n, 2, B64, W32, a.rows[3]);
     BNN_MARK(a.events, 5, s);
   } else if (net == NET_LFCW1A2) {
-    if (a.last_stage >= 1) BNN_LAUNCH((k_vec<AR_XNOR, 13, true, false, 1, 1>), grid_for(n, 32 / gpb_for(n, 32)), s, A64, B, a.rows[0], (int)n, 32, gpb_for(n, 32));
+    if (a.last_stage >= 1) BNN_STAGE((k_vec<AR_XNOR, 13, true, false, 1, 1>), (k_vec<AR_XNOR, 13, true, false, 1, 1, 8>), n, 32, A64, B, a.rows[0]);
     BNN_MARK(a.events, 2, s);
-    if (a.last_stage >= 2) BNN_LAUNCH((k_vec<AR_TB, 16, true, false, 1, 1>), grid_for(n, 32 / gpb_for(n, 32)), s, B64, A, a.rows[1], (int)n, 32, gpb_for(n, 32));
+    if (a.last_stage >= 2) BNN_STAGE((k_vec<AR_TB, 16, true, false, 1, 1>), (k_vec<AR_TB, 16, true, false, 1, 1, 8>), n, 32, B64, A, a.rows[1]);
     BNN_MARK(a.events, 3, s);
-    if (a.last_stage >= 3) BNN_LAUNCH((k_vec<AR_TB, 16, true, false, 1, 1>), grid_for(n, 32 / gpb_for(n, 32)), s, A64, B, a.rows[2], (int)n, 32, gpb_for(n, 32));
+    if (a.last_stage >= 3) BNN_STAGE((k_vec<AR_TB, 16, true, false, 1, 1>), (k_vec<AR_TB, 16, true, false, 1, 1, 8>), n, 32, A64, B, a.rows[2]);
     BNN_MARK(a.events, 4, s);
-    if (a.last_stage >= 4) BNN_LAUNCH((k_vec<AR_TB, 16, false, false, 1, 1>), grid_for(n, 2 / gpb_for(n, 2)), s, B64, reinterpret_cast<uint32_t *>(a.words), a.rows[3], (int)n, 2, gpb_for(n, 2));
+    if (a.last_stage >= 4) BNN_STAGE((k_vec<AR_TB, 16, false, false, 1, 1>), (k_vec<AR_TB, 16, false, false, 1, 1, 8>), n, 2, B64, W32, a.rows[3]);
     BNN_MARK(a.events, 5, s);
   } else {
     return hipErrorInvalidValue;
