@@ -284,30 +284,32 @@ __global__ __launch_bounds__(kBlock) void k_conv0_mfma(const uint8_t *__restrict
     bp[1][k] = (int)sw[1];
   }
   const v4i *__restrict__ atab = reinterpret_cast<const v4i *>(l0tab);
-  const int32_t *__restrict__ dtab = reinterpret_cast<const int32_t *>(l0tab + 64 * 32);
   uint32_t w0[2] = {0, 0}, w1[2] = {0, 0};  // this lane's pixel: [neuron tile], plane 0 / plane 1
+  const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int ct = 0; ct < 2; ct++) {
     const v4i a = atab[(32 * ct + r) * 2 + h];
+    v4i a2 = a;
+    if constexpr (OUT2) a2 = atab[(64 + 32 * ct + r) * 2 + h];  // the same rows with t1 folded in
 #pragma unroll
     for (int pt = 0; pt < 2; pt++) {
-      v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bp[pt], acc, 0, 0, 0);
-      int v[16], u[16];
+      const v16i acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bp[pt], zero, 0, 0, 0);
+      int v[16];
 #pragma unroll
       for (int i = 0; i < 16; i++) v[i] = acc[i];
       uint32_t y0, y1 = 0;
       if constexpr (!OUT2) {
         y0 = ~or_halves(sign_nibbles(v, h));  // collected !fire
       } else {
+        // second threshold: one more MFMA (the matrix pipe is idle anyway) instead of 16 adds; the
+        // planes are formed on the packed sign words, not per accumulator
+        const v16i acc2 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2, bp[pt], zero, 0, 0, 0);
+        int u[16];
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-          const int d = v[i] + dtab[32 * ct + (i & 3) + 8 * (i >> 2) + 4 * h];  // dot - t1 - 1
-          u[i] = v[i] ^ d;                                                     // f0 != f1
-          v[i] = v[i] & d;                                                     // !f0 & !f1: sign plane
-        }
-        y0 = or_halves(sign_nibbles(v, h));
-        y1 = ~or_halves(sign_nibbles(u, h));
+        for (int i = 0; i < 16; i++) u[i] = acc2[i];
+        const uint32_t n0 = sign_nibbles(v, h), n1 = sign_nibbles(u, h);  // !f0, !f1 of this half's 16 neurons
+        y0 = or_halves(n0 & n1);                                          // sign plane: neither fired
+        y1 = ~or_halves(n0 ^ n1);                                         // non-zero plane: f0 == f1
       }
       // both halves now hold the words of pixel r of tile pt; a lane keeps those of its own pixel
       const uint32_t mine = (pt == h) ? 0xFFFFFFFFu : 0u;
@@ -535,21 +537,21 @@ __device__ __forceinline__ int q_of(int m, int z, int neg_nzt) {
   else return (m << 1) - z;
 }
 
-// shift the decision(s) on g0 into the result word(s).  1-bit out: fire0.  2-bit out: the
-// planes are collected inverted (sign: f0|f1 ... see finish_bits) and fixed once per 32 neurons.
+// shift the decision(s) into the result word(s).  1-bit out: fire0.  2-bit out: b0 collects fire0
+// and b1 fire1, one v_alignbit each; the planes (sign = neither fired, non-zero = both or neither)
+// are formed from the two words once per group of neurons (finish_bits), not per neuron.
 template <bool OUT2>
 __device__ __forceinline__ void decide(uint32_t &b0, uint32_t &b1, int g0, int dt) {
-  if constexpr (!OUT2) {
-    b0 = shift_in_sign(b0, g0);
-  } else {
-    const int g1 = g0 + dt;
-    b0 = shift_in_sign(b0, g0 | g1);  // f0 | f1      -> sign plane    = ~
-    b1 = shift_in_sign(b1, g0 ^ g1);  // f0 != f1     -> non-zero plane = ~
-  }
+  b0 = shift_in_sign(b0, g0);
+  if constexpr (OUT2) b1 = shift_in_sign(b1, g0 + dt);
 }
 template <bool OUT2>
 __device__ __forceinline__ void finish_bits(uint32_t &b0, uint32_t &b1) {
-  if constexpr (OUT2) { b0 = ~b0; b1 = ~b1; }
+  if constexpr (OUT2) {
+    const uint32_t f0 = b0, f1 = b1;
+    b0 = ~(f0 | f1);
+    b1 = ~(f0 ^ f1);
+  }
 }
 
 // 3x3 valid conv, one lane = a 2x2 quad of output pixels (4x4 window in VGPRs), optional pool.

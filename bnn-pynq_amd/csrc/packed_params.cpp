@@ -117,21 +117,21 @@ void layout_header(const NetSpec &net, PackedHeader &h) {
 void fill_l0_mfma(const NetSpec &net, const RawParams &raw, uint8_t *dst) {
   const LayerSpec &L = net.L[0];
   const LayerView F{&L, &raw.w[0], &raw.t[0]};
-  int8_t *a = reinterpret_cast<int8_t *>(dst);
-  int32_t *dt = reinterpret_cast<int32_t *>(dst + 64 * 32);
-  for (int n = 0; n < 64; n++) {
-    for (int k = 0; k < 32; k++) a[n * 32 + k] = 0;
-    for (int c = 0; c < 3; c++)
-      for (int ky = 0; ky < 3; ky++)
-        for (int kx = 0; kx < 3; kx++) a[n * 32 + 3 * (c * 3 + ky) + kx] = (int8_t)F.weight(n, (ky * 3 + kx) * 3 + c);
-    int32_t T0 = F.threshold(n, 0), T1 = (L.nthr > 1) ? F.threshold(n, 1) : T0;
-    int32_t t0 = floor_div2(T0), t1 = floor_div2(T1);
-    const int32_t t0c = t0 > 3456 ? 3456 : (t0 < -3457 ? -3457 : t0);  // |dot| <= 27*128: same decisions
-    const int32_t v = -t0c - 1;
-    const int32_t a1 = (v + 32 + 64 * 128) / 64 - 128;  // floor((v + 32) / 64)
-    a[n * 32 + 27] = (int8_t)(v - 64 * a1);
-    a[n * 32 + 28] = (int8_t)a1;
-    dt[n] = t0c - t1;
+  for (int which = 0; which < 2; which++) {
+    int8_t *a = reinterpret_cast<int8_t *>(dst) + which * 64 * 32;
+    for (int n = 0; n < 64; n++) {
+      for (int k = 0; k < 32; k++) a[n * 32 + k] = 0;
+      for (int c = 0; c < 3; c++)
+        for (int ky = 0; ky < 3; ky++)
+          for (int kx = 0; kx < 3; kx++) a[n * 32 + 3 * (c * 3 + ky) + kx] = (int8_t)F.weight(n, (ky * 3 + kx) * 3 + c);
+      const int32_t T = F.threshold(n, (which && L.nthr > 1) ? 1 : 0);
+      const int32_t t = floor_div2(T);
+      const int32_t tc = t > 3456 ? 3456 : (t < -3457 ? -3457 : t);  // |dot| <= 27*128: same decisions
+      const int32_t v = -tc - 1;
+      const int32_t a1 = (v + 32 + 64 * 128) / 64 - 128;  // floor((v + 32) / 64)
+      a[n * 32 + 27] = (int8_t)(v - 64 * a1);
+      a[n * 32 + 28] = (int8_t)a1;
+    }
   }
 }
 

@@ -44,7 +44,7 @@ namespace bnn {
 
 constexpr uint32_t kBlobMagic0 = 0x4D4E4E42u;  // "BNNM"
 constexpr uint32_t kBlobMagic1 = 0x35353349u;  // "I355"
-constexpr uint32_t kBlobVersion = 1;
+constexpr uint32_t kBlobVersion = 2;
 
 struct PackedLayer {
   uint32_t offset;      // bytes from blob start, 256-byte aligned
@@ -61,11 +61,12 @@ struct PackedHeader {
   PackedLayer layer[9];
 };
 
-// Layer 0 for the matrix pipe: 64 rows of 32 int8 = {27 taps in the order of the AR_INT8 rows, a0, a1, 0, 0, 0}
-// with  a0 + 64*a1 = -t0 - 1  (t0 clamped to the reachable range of the dot product, +-3456), followed by
-// 64 int32  t0 - t1  (second threshold of the 2-bit nets).  The activation operand carries the
-// constants 1 and 64 in K slots 27 and 28, so the MFMA result is  dot - t0 - 1 : its sign bit is !fire.
-constexpr uint32_t kL0MfmaBytes = 64 * 32 + 64 * 4;
+// Layer 0 for the matrix pipe: two tables of 64 rows of 32 int8 = {27 taps in the order of the AR_INT8
+// rows, a0, a1, 0, 0, 0} with  a0 + 64*a1 = -t - 1  (t clamped to the reachable range of the dot
+// product, +-3456): the first with t = t0, the second with t = t1 (second threshold of the 2-bit
+// nets; a copy of the first for the 1-bit net).  The activation operand carries the constants 1 and
+// 64 in K slots 27 and 28, so the MFMA result is  dot - t - 1 : its sign bit is !fire.
+constexpr uint32_t kL0MfmaBytes = 2 * 64 * 32;
 static_assert(sizeof(PackedHeader) == 32 + 9 * 16, "blob header layout");
 
 uint32_t row_dwords_for(const LayerSpec &L);

@@ -36,7 +36,7 @@ def test_blob_matches_oracle_weights(network, dataset):
     blob = gl.pack_params(network, gl.param_dir(dataset, network))
     o = ol.Oracle(network, ol.param_dir(dataset, network))
     magic0, magic1, version, net_id, nlayers, total, _, _ = struct.unpack_from("<8I", blob, 0)
-    assert (magic0, magic1, version) == (0x4D4E4E42, 0x35353349, 1)
+    assert (magic0, magic1, version) == (0x4D4E4E42, 0x35353349, 2)
     assert total == blob.size and nlayers == o.nl
     for l in range(nlayers):
         off, rd, rows, kw = struct.unpack_from("<4I", blob, 32 + 16 * l)
@@ -87,24 +87,22 @@ def test_blob_matches_oracle_weights(network, dataset):
 
 @pytest.mark.parametrize("network,dataset", [s for s in SETS if s[0].startswith("cnv")], ids=lambda x: x)
 def test_layer0_mfma_table(network, dataset):
-    """the matrix-pipe copy of layer 0: taps in the AR_INT8 order, threshold folded into K slots 27/28
-    (a0 + 64*a1 = -clamp(t0) - 1 with |a0| <= 32), second threshold as t0c - t1"""
+    """the matrix-pipe copy of layer 0: two tables (first / second threshold), taps in the AR_INT8 order,
+    the threshold folded into K slots 27/28 (a0 + 64*a1 = -clamp(t) - 1 with |a0| <= 32)"""
     blob = gl.pack_params(network, gl.param_dir(dataset, network))
     o = ol.Oracle(network, ol.param_dir(dataset, network))
     off = struct.unpack_from("<I", blob, 24)[0]
     assert off and off % 256 == 0
-    A = blob[off: off + 64 * 32].copy().view(np.int8).reshape(64, 32)
-    dt = blob[off + 64 * 32: off + 64 * 32 + 256].copy().view(np.int32)
     W = o.weights(0)
-    assert (A[:, :27] == W.reshape(64, 3, 3, 3).transpose(0, 3, 1, 2).reshape(64, 27)).all()
-    assert (A[:, 29:] == 0).all()
     nthr = 2 if network.endswith("A2") else 1
-    for n in range(64):
-        t0 = o.L.bnn_oracle_threshold(o.h, 0, n, 0) >> 1
-        t1 = (o.L.bnn_oracle_threshold(o.h, 0, n, 1) >> 1) if nthr == 2 else t0
-        t0c = min(3456, max(-3457, t0))
-        assert int(A[n, 27]) + 64 * int(A[n, 28]) == -t0c - 1 and abs(int(A[n, 27])) <= 32
-        assert dt[n] == t0c - t1
+    for which in range(2):
+        A = blob[off + which * 2048: off + (which + 1) * 2048].copy().view(np.int8).reshape(64, 32)
+        assert (A[:, :27] == W.reshape(64, 3, 3, 3).transpose(0, 3, 1, 2).reshape(64, 27)).all()
+        assert (A[:, 29:] == 0).all()
+        for n in range(64):
+            t = o.L.bnn_oracle_threshold(o.h, 0, n, which if nthr == 2 else 0) >> 1
+            tc = min(3456, max(-3457, t))
+            assert int(A[n, 27]) + 64 * int(A[n, 28]) == -tc - 1 and abs(int(A[n, 27])) <= 32
     # clamping never changes a decision: |dot| <= 27 * 128
     d = np.arange(-3456, 3457)
     for t in (-(1 << 22), -3458, -3457, -3456, 0, 3455, 3456, 3457, 1 << 22):
