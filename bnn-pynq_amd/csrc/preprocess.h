@@ -23,4 +23,9 @@ struct ResampleJob {
 
 hipError_t launch_image_to_cifar(const ResampleJob &job, hipStream_t s);
 
+// Records of an input file as they lie on disk -> packed image bodies: drops the first `skip` bytes of
+// every `rec_bytes`-byte record (the label byte of a CIFAR-10 record).  `raw` starts at a record
+// boundary and is 4-byte aligned; img_bytes = rec_bytes - skip is a multiple of 4.
+hipError_t launch_strip_records(const uint8_t *raw, int rec_bytes, int skip, uint8_t *out, int n_records, hipStream_t s);
+
 }  // namespace bnn

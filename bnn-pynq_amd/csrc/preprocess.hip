@@ -121,7 +121,29 @@ __global__ __launch_bounds__(256) void k_resample_v(const uint8_t *__restrict__ 
   dst[(size_t)yy * cols + c] = clip8(s);
 }
 
+// parse_cifar10 on the device: record i = [label][3072 bytes] at byte 3073 i.  One lane per output
+// dword; the source is unaligned by (3073 i + 1) % 4, so two aligned dwords and a v_alignbyte.
+__global__ __launch_bounds__(256) void k_strip_records(const uint32_t *__restrict__ raw, int rec_bytes, int skip, uint32_t *__restrict__ out,
+                                                        int img_dwords, size_t n_dwords) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_dwords) return;
+  const size_t rec = t / img_dwords;
+  const int j = (int)(t - rec * img_dwords);
+  const size_t a = rec * (size_t)rec_bytes + skip + 4 * (size_t)j;  // byte address of the source dword
+  const uint32_t lo = raw[a >> 2], hi = raw[(a >> 2) + 1];          // (the buffer has 4 bytes of slack)
+  out[t] = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(a & 3));
+}
+
 }  // namespace
+
+hipError_t launch_strip_records(const uint8_t *raw, int rec_bytes, int skip, uint8_t *out, int n_records, hipStream_t s) {
+  const int img_dwords = (rec_bytes - skip) / 4;
+  const size_t n = (size_t)n_records * img_dwords;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_strip_records, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const uint32_t *>(raw), rec_bytes,
+                     skip, reinterpret_cast<uint32_t *>(out), img_dwords, n);
+  return hipGetLastError();
+}
 
 hipError_t launch_image_to_cifar(const ResampleJob &j, hipStream_t s) {
   const bool horizontal = j.out_w != j.w;

@@ -6,7 +6,7 @@
 // the per-network bnn/src/network/<net>/sw/main_python.cpp):
 //   FoldedMVInit / FoldedMVDeinit            -> Workspace (HBM buffers, lazily sized)
 //   FoldedMVLoadLayerMem / DoMemInit         -> packed_params.cpp + one hipMemcpy
-//   parse_cifar10 / parse_mnist_images       -> read_cifar_file / read_mnist_file
+//   parse_cifar10 / parse_mnist_images       -> open_image_file + k_strip_records (file streamed to HBM as it lies on disk)
 //   quantiseAndPack / binarizeAndPack        -> done on the GPU (k_conv0 / k_lfc_binarize)
 //   BlackBoxJam(.., numReps)                 -> run_cnv / run_lfc (kernels.hip)
 //   copyFromLowPrecBuffer + argmax / log2    -> k_fclast / host decode below
@@ -15,12 +15,19 @@
 // every inference entry point fails loudly (message on stderr, NULL / -1).
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/bnn_mi355x.h"
@@ -67,6 +74,11 @@ struct Runtime {
   hipStream_t stream = nullptr, copy_stream = nullptr;
   hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
   std::vector<hipEvent_t> time_events;
+  // file path: records as they lie on disk, two host chunks (filled by reader threads) and two HBM chunks
+  size_t file_cap = 0;
+  std::unique_ptr<uint8_t[]> h_file[2];
+  uint8_t *d_file[2] = {nullptr, nullptr};
+  hipEvent_t file_sent[2] = {nullptr, nullptr};
   // picture -> CIFAR record (bnn_mi355x_images_to_cifar): source picture, horizontal-pass output,
   // coefficient tables, records
   size_t pp_src_cap = 0, pp_tmp_cap = 0, pp_coef_cap = 0, pp_rec_cap = 0;
@@ -129,7 +141,7 @@ int upload_blob() {
 
 void free_workspace() {
   Runtime &r = rt();
-  if (r.cap == 0 && r.stage_cap == 0 && r.res_cap == 0 && !r.d_pp_src && !r.d_pp_rec) return;
+  if (r.cap == 0 && r.stage_cap == 0 && r.res_cap == 0 && !r.d_pp_src && !r.d_pp_rec && !r.file_cap) return;
   if (r.device >= 0) (void)hipSetDevice(r.device);
   (void)hipDeviceSynchronize();
   (void)hipFree(r.buf0); (void)hipFree(r.buf1); (void)hipFree(r.d_images[0]); (void)hipFree(r.d_images[1]);
@@ -138,6 +150,10 @@ void free_workspace() {
   r.d_scores = nullptr; r.d_classes = nullptr; r.d_words = nullptr;
   r.cap = r.stage_cap = 0;
   r.res_cap = 0;
+  (void)hipFree(r.d_file[0]); (void)hipFree(r.d_file[1]);
+  r.d_file[0] = r.d_file[1] = nullptr;
+  r.h_file[0].reset(); r.h_file[1].reset();
+  r.file_cap = 0;
   (void)hipFree(r.d_pp_src); (void)hipFree(r.d_pp_tmp); (void)hipFree(r.d_pp_rec); (void)hipFree(r.d_pp_coef);
   r.d_pp_src = r.d_pp_tmp = r.d_pp_rec = nullptr;
   r.d_pp_coef = nullptr;
@@ -339,6 +355,164 @@ int read_images(const char *path, std::vector<uint8_t> &imgs) {
   return rt().spec.is_cnv ? read_cifar_file(path, imgs) : read_mnist_file(path, imgs);
 }
 
+// ---- input files, streamed ---------------------------------------------------
+// The batched entry points do not parse the file on the host: the records go to HBM as they lie on
+// disk (reader threads pread() chunk c+1 while chunk c is copied and classified) and the label
+// bytes are dropped by a kernel (k_strip_records).  An MNIST body needs no kernel at all.
+struct ImageFile {
+  int fd = -1;
+  size_t n = 0;            // images
+  size_t rec = 0, skip = 0;  // bytes per record on disk, bytes to drop at the start of each
+  size_t first = 0;        // file offset of record 0
+  ~ImageFile() { if (fd >= 0) ::close(fd); }
+};
+
+int open_image_file(const char *path, ImageFile &f) {
+  Runtime &r = rt();
+  f.fd = ::open(path ? path : "", O_RDONLY);
+  struct stat st;
+  if (f.fd < 0 || ::fstat(f.fd, &st) != 0) return fail(std::string("Could not open file ") + (path ? path : ""));
+  const size_t size = (size_t)st.st_size;
+  if (r.spec.is_cnv) {  // whole records only, like the fread loop of read_cifar_file
+    f.rec = 3073; f.skip = 1; f.first = 0;
+    f.n = size / 3073;
+  } else {
+    unsigned char h[16];
+    if (::pread(f.fd, h, 16, 0) != 16) return fail("MNIST image file: short header");
+    auto be = [&](int o) { return ((uint32_t)h[o] << 24) | ((uint32_t)h[o + 1] << 16) | ((uint32_t)h[o + 2] << 8) | h[o + 3]; };
+    if (be(0) != 0x803u || be(8) != 28 || be(12) != 28) return fail("MNIST image file: bad header");
+    f.rec = 784; f.skip = 0; f.first = 16;
+    f.n = be(4);
+    if (size < 16 + f.n * 784) return fail("MNIST image file: truncated");
+  }
+  if (f.n > 0x7FFFFFFFu) return fail("input file: too many images for the int-sized ABI");
+  return 0;
+}
+
+// pread() [offset, offset + bytes) into dst on up to 8 threads (a single thread moves page-cache
+// data at a fraction of what the PCIe link takes)
+struct ChunkReader {
+  std::vector<std::thread> threads;
+  std::atomic<bool> ok{true};
+  void start(int fd, size_t offset, size_t bytes, uint8_t *dst) {
+    ok = true;
+    const size_t hw = std::thread::hardware_concurrency();
+    size_t nt = bytes / (4u << 20) + 1;
+    if (nt > 8) nt = 8;
+    if (hw && nt > hw) nt = hw;
+    const size_t part = ((bytes + nt - 1) / nt + 4095) & ~(size_t)4095;
+    for (size_t t = 0; t < nt; t++) {
+      const size_t lo = t * part, hi = (lo + part < bytes) ? lo + part : bytes;
+      if (lo >= hi) break;
+      threads.emplace_back([this, fd, offset, dst, lo, hi] {
+        size_t done = lo;
+        while (done < hi) {
+          const ssize_t got = ::pread(fd, dst + done, hi - done, (off_t)(offset + done));
+          if (got <= 0) { ok = false; return; }
+          done += (size_t)got;
+        }
+      });
+    }
+  }
+  bool wait() {
+    for (auto &t : threads) t.join();
+    threads.clear();
+    return ok;
+  }
+  ~ChunkReader() { (void)wait(); }
+};
+
+// images [0, n) of an open file -> any of classes / scores / words (host arrays).  Same contract as
+// infer_host; the timed region is again the compute stages alone.
+int infer_file(const ImageFile &f, int n, int ncls, int32_t *classes, int16_t *scores, uint64_t *words, float *usec) {
+  Runtime &r = rt();
+  if (!ready()) return -1;
+  if (ncls < 1 || ncls > 64) return fail("number_class must be in 1..64");
+  if (usec) *usec = 0.f;
+  if (n <= 0) return 0;
+  const size_t isz = (size_t)r.spec.image_bytes();
+  const int chunk = n < kHostChunk ? n : kHostChunk;
+  const int nchunks = (n + chunk - 1) / chunk;
+  if (reserve(chunk) || reserve_host(chunk, (size_t)n)) return -1;
+  const size_t chunk_bytes = (size_t)chunk * f.rec;
+  if (chunk_bytes > r.file_cap) {
+    HIP_OK(hipDeviceSynchronize());
+    for (int i = 0; i < 2; i++) {
+      (void)hipFree(r.d_file[i]);
+      r.d_file[i] = nullptr;
+      r.h_file[i].reset();
+    }
+    r.file_cap = 0;
+    for (int i = 0; i < 2; i++) {
+      r.h_file[i].reset(new (std::nothrow) uint8_t[chunk_bytes + 8]);
+      if (!r.h_file[i]) return fail("out of memory");
+      if (f.skip) HIP_OK(hipMalloc(reinterpret_cast<void **>(&r.d_file[i]), chunk_bytes + 256));
+      if (!r.file_sent[i]) HIP_OK(hipEventCreateWithFlags(&r.file_sent[i], hipEventDisableTiming));
+    }
+    r.file_cap = chunk_bytes;
+  } else if (f.skip && !r.d_file[0]) {
+    for (int i = 0; i < 2; i++) HIP_OK(hipMalloc(reinterpret_cast<void **>(&r.d_file[i]), r.file_cap + 256));
+  }
+  while ((int)r.time_events.size() < 2 * nchunks) {
+    hipEvent_t e;
+    HIP_OK(hipEventCreate(&e));
+    r.time_events.push_back(e);
+  }
+  const bool want_scores = scores && r.spec.is_cnv;
+  ChunkReader reader;
+  auto span = [&](int c, size_t *off, int *m) {
+    const int base = c * chunk;
+    *m = (n - base < chunk) ? n - base : chunk;
+    *off = f.first + (size_t)base * f.rec;
+  };
+  size_t off;
+  int m;
+  span(0, &off, &m);
+  reader.start(f.fd, off, (size_t)m * f.rec, r.h_file[0].get());
+  for (int c = 0; c < nchunks; c++) {
+    const int base = c * chunk, slot = c & 1;
+    span(c, &off, &m);
+    if (!reader.wait()) return fail("input file: read error");
+    if (c + 1 < nchunks) {  // the other host chunk is free once its copy (chunk c-1) has left it
+      if (c >= 1) HIP_OK(hipEventSynchronize(r.file_sent[slot ^ 1]));
+      size_t off2;
+      int m2;
+      span(c + 1, &off2, &m2);
+      reader.start(f.fd, off2, (size_t)m2 * f.rec, r.h_file[slot ^ 1].get());
+    }
+    if (c >= 2) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));
+    uint8_t *dst = f.skip ? r.d_file[slot] : r.d_images[slot];
+    HIP_OK(hipMemcpyAsync(dst, r.h_file[slot].get(), (size_t)m * f.rec, hipMemcpyHostToDevice, r.copy_stream));
+    HIP_OK(hipEventRecord(r.file_sent[slot], r.copy_stream));
+    if (f.skip) {
+      const hipError_t e = launch_strip_records(r.d_file[slot], (int)f.rec, (int)f.skip, r.d_images[slot], m, r.copy_stream);
+      if (e != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(e));
+    }
+    HIP_OK(hipEventRecord(r.copied[slot], r.copy_stream));
+    HIP_OK(hipStreamWaitEvent(r.stream, r.copied[slot], 0));
+    HIP_OK(hipEventRecord(r.time_events[2 * c], r.stream));
+    if (enqueue(r.d_images[slot], m, ncls, classes ? r.d_classes + base : nullptr, want_scores ? r.d_scores + (size_t)base * 64 : nullptr,
+                r.d_words + base, r.stream))
+      return -1;
+    HIP_OK(hipEventRecord(r.time_events[2 * c + 1], r.stream));
+    HIP_OK(hipEventRecord(r.consumed[slot], r.stream));
+  }
+  (void)isz;
+  if (classes) HIP_OK(hipMemcpyAsync(classes, r.d_classes, (size_t)n * 4, hipMemcpyDeviceToHost, r.stream));
+  if (want_scores) HIP_OK(hipMemcpyAsync(scores, r.d_scores, (size_t)n * 128, hipMemcpyDeviceToHost, r.stream));
+  if (words && !r.spec.is_cnv) HIP_OK(hipMemcpyAsync(words, r.d_words, (size_t)n * 8, hipMemcpyDeviceToHost, r.stream));
+  HIP_OK(hipStreamSynchronize(r.stream));
+  HIP_OK(hipStreamSynchronize(r.copy_stream));
+  double total_ms = 0.0;
+  for (int c = 0; c < nchunks; c++) {
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, r.time_events[2 * c], r.time_events[2 * c + 1]));
+    total_ms += ms;
+  }
+  if (usec) *usec = (float)(total_ms * 1000.0 / n);
+  return 0;
+}
+
 // ---- LFC host decode (libm, like the reference) -------------------------------
 uint64_t label_mask(int ncls) { return 0xFFFFFFFFFFFFFFFFull >> (64 - ncls); }
 // batched: (unsigned) log2((double) word), 0 when no bit is set (foldedmv-offload.cpp:213-220)
@@ -352,12 +526,15 @@ int lfc_hot_single(uint64_t w, int ncls) {
   return w ? (int)(unsigned int)std::round(std::log2((double)w)) : 0;
 }
 
-int *classify_host(const uint8_t *imgs, int n, int ncls, float *usec, int enable_detail) {
+// the result array of inference_multiple: class indices, or (CNV, enable_detail) number_class scores
+// per image.  `infer(classes, scores, words)` runs the batch from wherever the images are.
+template <typename Infer>
+int *classify_with(Infer infer, int n, int ncls, int enable_detail) {
   Runtime &r = rt();
   int *result = nullptr;
   if (r.spec.is_cnv && enable_detail) {
     std::vector<int16_t> s((size_t)n * 64);
-    if (infer_host(imgs, n, ncls, nullptr, s.data(), nullptr, usec)) return nullptr;
+    if (infer(nullptr, s.data(), nullptr)) return nullptr;
     result = new (std::nothrow) int[(size_t)(n > 0 ? n : 1) * ncls];
     if (!result) { fail("out of memory"); return nullptr; }
     for (int i = 0; i < n; i++)
@@ -365,16 +542,21 @@ int *classify_host(const uint8_t *imgs, int n, int ncls, float *usec, int enable
   } else if (r.spec.is_cnv) {
     result = new (std::nothrow) int[(size_t)(n > 0 ? n : 1)];
     if (!result) { fail("out of memory"); return nullptr; }
-    if (infer_host(imgs, n, ncls, result, nullptr, nullptr, usec)) { delete[] result; return nullptr; }
+    if (infer(result, nullptr, nullptr)) { delete[] result; return nullptr; }
   } else {
     // the LFC libraries ignore enable_detail (lfcW1A1/sw/main_python.cpp:135-156)
     std::vector<uint64_t> w((size_t)(n > 0 ? n : 1));
-    if (infer_host(imgs, n, ncls, nullptr, nullptr, w.data(), usec)) return nullptr;
+    if (infer(nullptr, nullptr, w.data())) return nullptr;
     result = new (std::nothrow) int[(size_t)(n > 0 ? n : 1)];
     if (!result) { fail("out of memory"); return nullptr; }
     for (int i = 0; i < n; i++) result[i] = lfc_class_batched(w[i], ncls);
   }
   return result;
+}
+
+int *classify_host(const uint8_t *imgs, int n, int ncls, float *usec, int enable_detail) {
+  return classify_with([&](int32_t *c, int16_t *s, uint64_t *w) { return infer_host(imgs, n, ncls, c, s, w, usec); }, n, ncls,
+                       enable_detail);
 }
 
 }  // namespace
@@ -400,16 +582,15 @@ void load_parameters(const char *path) {
 int inference(const char *path, int results[64], int number_class, float *usecPerImage) {
   Runtime &r = rt();
   if (!ready()) return -1;
-  std::vector<uint8_t> imgs;
-  const int n = read_images(path, imgs);
-  if (n < 0) return -1;
-  if (n == 0) return fail("no image in input file");
+  ImageFile f;
+  if (open_image_file(path, f)) return -1;
+  if (f.n == 0) return fail("no image in input file");
   float usec = 0.f;
   int cls;
   if (r.spec.is_cnv) {
-    // testPrebuiltCIFAR10_from_image: count = 1 (foldedmv-offload.h:318)
+    // testPrebuiltCIFAR10_from_image: count = 1 (foldedmv-offload.h:318): the first record of the file
     int16_t s[64];
-    if (infer_host(imgs.data(), 1, number_class, nullptr, s, nullptr, &usec)) return -1;
+    if (infer_file(f, 1, number_class, nullptr, s, nullptr, &usec)) return -1;
     if (results)
       for (int j = 0; j < number_class; j++) results[j] = s[j];
     cls = 0;
@@ -417,7 +598,7 @@ int inference(const char *path, int results[64], int number_class, float *usecPe
       if (s[j] > s[cls]) cls = j;  // std::max_element: first maximum
   } else {
     uint64_t w = 0;
-    if (infer_host(imgs.data(), 1, number_class, nullptr, nullptr, &w, &usec)) return -1;
+    if (infer_file(f, 1, number_class, nullptr, nullptr, &w, &usec)) return -1;
     const int hot = lfc_hot_single(w, number_class);
     if (results)
       for (int i = 0; i < 64; i++) results[i] = (i == hot) ? 1 : 0;
@@ -432,11 +613,12 @@ int inference(const char *path, int results[64], int number_class, float *usecPe
 int *inference_multiple(const char *path, int number_class, int *image_number, float *usecPerImage,
                         int enable_detail) {
   if (!ready()) return nullptr;
-  std::vector<uint8_t> imgs;
-  const int n = read_images(path, imgs);
-  if (n < 0) return nullptr;
+  ImageFile f;
+  if (open_image_file(path, f)) return nullptr;
+  const int n = (int)f.n;
   float usec = 0.f;
-  int *res = classify_host(imgs.data(), n, number_class, &usec, enable_detail);
+  int *res = classify_with([&](int32_t *c, int16_t *s, uint64_t *w) { return infer_file(f, n, number_class, c, s, w, &usec); }, n,
+                           number_class, enable_detail);
   if (!res) return nullptr;
   std::printf("Inference took %.0f microseconds, %g usec per image\n", usec * n, usec);
   std::printf("Classification rate: %g images per second\n", 1000000.0 / usec);

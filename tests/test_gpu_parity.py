@@ -315,6 +315,58 @@ def test_abi_edge_behaviour(tmp_path):
     assert net.raw(imgs).shape == (4, 64)                        # still healthy afterwards
 
 
+@pytest.mark.parametrize("network,dataset,n", [("cnvW1A1", "cifar10", 70001), ("cnvW2A2", "cifar10", 33000),
+                                               ("lfcW1A1", "mnist", 100003), ("lfcW1A2", "mnist", 40000)])
+def test_file_abi_streams_multi_chunk_files(network, dataset, n, tmp_path):
+    """inference_multiple on files of several 32768-image chunks (the records go to HBM as they lie on disk,
+    reader threads one chunk ahead, labels stripped by a kernel): same classes as the in-memory entry
+    point, detail scores included; inference() classifies the first record only"""
+    net = gpu_net(network, dataset)
+    L = net.L
+    cnv = network.startswith("cnv")
+    imgs = rand_images(network, n, 77, "uniform")
+    path = tmp_path / "big.bin"
+    with open(path, "wb") as f:
+        if cnv:
+            rec = np.empty((n, 3073), np.uint8)
+            rec[:, 0] = np.arange(n) % 10
+            rec[:, 1:] = imgs
+            f.write(rec.tobytes())
+        else:
+            f.write((0x803).to_bytes(4, "big") + n.to_bytes(4, "big") + (28).to_bytes(4, "big") * 2)
+            f.write(imgs.tobytes())
+    want = net.classify(imgs, 10)
+    cnt, usec = C.c_int(0), C.c_float(0)
+    p = L.inference_multiple(str(path).encode(), 10, C.byref(cnt), C.byref(usec), 0)
+    assert p and cnt.value == n and usec.value > 0
+    got = np.ctypeslib.as_array(p, (n,)).copy()
+    L.free_results(p)
+    assert (got == want).all()
+    if cnv:
+        p = L.inference_multiple(str(path).encode(), 10, C.byref(cnt), None, 1)
+        det = np.ctypeslib.as_array(p, (n * 10,)).copy().reshape(n, 10)
+        L.free_results(p)
+        assert (det == net.raw(imgs)[:, :10]).all()
+        res = (C.c_int * 64)()
+        cls = L.inference(str(path).encode(), res, 10, None)
+        assert list(res[:10]) == det[0].tolist() and cls == int(np.argmax(det[0]))
+    else:
+        res = (C.c_int * 64)()
+        cls = L.inference(str(path).encode(), res, 10, None)
+        assert sum(res) <= 1 and (sum(res) == 0 or res[cls] == 1)
+    # a second, smaller file right after a big one (buffers are reused)
+    small = tmp_path / "small.bin"
+    with open(small, "wb") as f:
+        if cnv:
+            f.write(rec[:5].tobytes())
+        else:
+            f.write((0x803).to_bytes(4, "big") + (5).to_bytes(4, "big") + (28).to_bytes(4, "big") * 2)
+            f.write(imgs[:5].tobytes())
+    p = L.inference_multiple(str(small).encode(), 10, C.byref(cnt), None, 0)
+    assert cnt.value == 5 and list(p[:5]) == want[:5].tolist()
+    L.free_results(p)
+
+
 def test_layer0_integer_pipe_kernel_agrees():
     """BNN_MI355X_L0=valu selects k_conv0 (v_dot4c) instead of the MFMA first layer: same bits"""
     import subprocess
