@@ -79,6 +79,8 @@ struct Runtime {
   std::unique_ptr<uint8_t[]> h_file[2];
   uint8_t *d_file[2] = {nullptr, nullptr};
   hipEvent_t file_sent[2] = {nullptr, nullptr};
+  uint8_t *d_all = nullptr;  // a whole input file's images, resident (fault campaigns)
+  size_t all_cap = 0;
   // picture -> CIFAR record (bnn_mi355x_images_to_cifar): source picture, horizontal-pass output,
   // coefficient tables, records
   size_t pp_src_cap = 0, pp_tmp_cap = 0, pp_coef_cap = 0, pp_rec_cap = 0;
@@ -141,7 +143,7 @@ int upload_blob() {
 
 void free_workspace() {
   Runtime &r = rt();
-  if (r.cap == 0 && r.stage_cap == 0 && r.res_cap == 0 && !r.d_pp_src && !r.d_pp_rec && !r.file_cap) return;
+  if (r.cap == 0 && r.stage_cap == 0 && r.res_cap == 0 && !r.d_pp_src && !r.d_pp_rec && !r.file_cap && !r.all_cap) return;
   if (r.device >= 0) (void)hipSetDevice(r.device);
   (void)hipDeviceSynchronize();
   (void)hipFree(r.buf0); (void)hipFree(r.buf1); (void)hipFree(r.d_images[0]); (void)hipFree(r.d_images[1]);
@@ -150,6 +152,9 @@ void free_workspace() {
   r.d_scores = nullptr; r.d_classes = nullptr; r.d_words = nullptr;
   r.cap = r.stage_cap = 0;
   r.res_cap = 0;
+  (void)hipFree(r.d_all);
+  r.d_all = nullptr;
+  r.all_cap = 0;
   (void)hipFree(r.d_file[0]); (void)hipFree(r.d_file[1]);
   r.d_file[0] = r.d_file[1] = nullptr;
   r.h_file[0].reset(); r.h_file[1].reset();
@@ -316,47 +321,12 @@ int infer_host(const uint8_t *imgs, int n, int ncls, int32_t *classes, int16_t *
   return 0;
 }
 
-// ---- input files ------------------------------------------------------------
-// CIFAR-10 binary: records of [label u8][R 1024][G 1024][B 1024] (tiny-cnn
-// parse_cifar10, call site main_python.cpp:129,152).  Bodies are passed to the
-// GPU as they are: planar CHW uint8.
-int read_cifar_file(const char *path, std::vector<uint8_t> &imgs) {
-  FILE *f = std::fopen(path, "rb");
-  if (!f) return fail(std::string("Could not open file ") + path);
-  std::vector<uint8_t> rec(3073);
-  imgs.clear();
-  int n = 0;
-  while (std::fread(rec.data(), 1, 3073, f) == 3073) {
-    imgs.insert(imgs.end(), rec.begin() + 1, rec.end());
-    n++;
-  }
-  std::fclose(f);
-  return n;
-}
-
-// MNIST idx3: 16-byte big-endian header (magic 0x803, count, rows, cols), then
-// count x 784 uint8 (tiny-cnn parse_mnist_images, lfcW1A1/sw/main_python.cpp:122,144)
-int read_mnist_file(const char *path, std::vector<uint8_t> &imgs) {
-  FILE *f = std::fopen(path, "rb");
-  if (!f) return fail(std::string("Could not open file ") + path);
-  unsigned char h[16];
-  if (std::fread(h, 1, 16, f) != 16) { std::fclose(f); return fail("MNIST image file: short header"); }
-  auto be = [&](int o) { return ((uint32_t)h[o] << 24) | ((uint32_t)h[o + 1] << 16) | ((uint32_t)h[o + 2] << 8) | h[o + 3]; };
-  if (be(0) != 0x803u || be(8) != 28 || be(12) != 28) { std::fclose(f); return fail("MNIST image file: bad header"); }
-  const uint32_t n = be(4);
-  imgs.assign((size_t)n * 784, 0);
-  const size_t got = n ? std::fread(imgs.data(), 1, imgs.size(), f) : 0;
-  std::fclose(f);
-  if (got != imgs.size()) return fail("MNIST image file: truncated");
-  return (int)n;
-}
-
-int read_images(const char *path, std::vector<uint8_t> &imgs) {
-  return rt().spec.is_cnv ? read_cifar_file(path, imgs) : read_mnist_file(path, imgs);
-}
-
 // ---- input files, streamed ---------------------------------------------------
-// The batched entry points do not parse the file on the host: the records go to HBM as they lie on
+// CIFAR-10 binary: records of [label u8][R 1024][G 1024][B 1024] (tiny-cnn parse_cifar10, call site
+// main_python.cpp:129,152); bodies go to the GPU as they are, planar CHW uint8.  MNIST idx3: 16-byte
+// big-endian header (magic 0x803, count, rows, cols), then count x 784 uint8 (tiny-cnn
+// parse_mnist_images, lfcW1A1/sw/main_python.cpp:122,144).
+// The entry points do not parse the file on the host: the records go to HBM as they lie on
 // disk (reader threads pread() chunk c+1 while chunk c is copied and classified) and the label
 // bytes are dropped by a kernel (k_strip_records).  An MNIST body needs no kernel at all.
 struct ImageFile {
@@ -422,18 +392,16 @@ struct ChunkReader {
   ~ChunkReader() { (void)wait(); }
 };
 
-// images [0, n) of an open file -> any of classes / scores / words (host arrays).  Same contract as
-// infer_host; the timed region is again the compute stages alone.
-int infer_file(const ImageFile &f, int n, int ncls, int32_t *classes, int16_t *scores, uint64_t *words, float *usec) {
+// Streams images [0, n) of an open file into HBM, a chunk of at most kHostChunk at a time (reader
+// threads one chunk ahead of the copy).  Chunk c lands packed (labels stripped) at dst(c, slot) and
+// `consume(c, base, m, slot)` is called once its copy and strip are enqueued on copy_stream and
+// r.stream has been made to wait for them.  reuse_slots: the destinations alternate between two
+// buffers, so a chunk's copy must wait until the stages of the chunk two before have consumed it.
+template <typename Dst, typename Consume>
+int stream_file(const ImageFile &f, int n, bool reuse_slots, Dst dst, Consume consume) {
   Runtime &r = rt();
-  if (!ready()) return -1;
-  if (ncls < 1 || ncls > 64) return fail("number_class must be in 1..64");
-  if (usec) *usec = 0.f;
-  if (n <= 0) return 0;
-  const size_t isz = (size_t)r.spec.image_bytes();
   const int chunk = n < kHostChunk ? n : kHostChunk;
   const int nchunks = (n + chunk - 1) / chunk;
-  if (reserve(chunk) || reserve_host(chunk, (size_t)n)) return -1;
   const size_t chunk_bytes = (size_t)chunk * f.rec;
   if (chunk_bytes > r.file_cap) {
     HIP_OK(hipDeviceSynchronize());
@@ -450,15 +418,7 @@ int infer_file(const ImageFile &f, int n, int ncls, int32_t *classes, int16_t *s
       if (!r.file_sent[i]) HIP_OK(hipEventCreateWithFlags(&r.file_sent[i], hipEventDisableTiming));
     }
     r.file_cap = chunk_bytes;
-  } else if (f.skip && !r.d_file[0]) {
-    for (int i = 0; i < 2; i++) HIP_OK(hipMalloc(reinterpret_cast<void **>(&r.d_file[i]), r.file_cap + 256));
   }
-  while ((int)r.time_events.size() < 2 * nchunks) {
-    hipEvent_t e;
-    HIP_OK(hipEventCreate(&e));
-    r.time_events.push_back(e);
-  }
-  const bool want_scores = scores && r.spec.is_cnv;
   ChunkReader reader;
   auto span = [&](int c, size_t *off, int *m) {
     const int base = c * chunk;
@@ -480,24 +440,52 @@ int infer_file(const ImageFile &f, int n, int ncls, int32_t *classes, int16_t *s
       span(c + 1, &off2, &m2);
       reader.start(f.fd, off2, (size_t)m2 * f.rec, r.h_file[slot ^ 1].get());
     }
-    if (c >= 2) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));
-    uint8_t *dst = f.skip ? r.d_file[slot] : r.d_images[slot];
-    HIP_OK(hipMemcpyAsync(dst, r.h_file[slot].get(), (size_t)m * f.rec, hipMemcpyHostToDevice, r.copy_stream));
+    if (c >= 2) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));  // d_file[slot] / dst free again
+    uint8_t *packed = dst(c, slot);
+    uint8_t *to = f.skip ? r.d_file[slot] : packed;
+    HIP_OK(hipMemcpyAsync(to, r.h_file[slot].get(), (size_t)m * f.rec, hipMemcpyHostToDevice, r.copy_stream));
     HIP_OK(hipEventRecord(r.file_sent[slot], r.copy_stream));
     if (f.skip) {
-      const hipError_t e = launch_strip_records(r.d_file[slot], (int)f.rec, (int)f.skip, r.d_images[slot], m, r.copy_stream);
+      const hipError_t e = launch_strip_records(r.d_file[slot], (int)f.rec, (int)f.skip, packed, m, r.copy_stream);
       if (e != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(e));
     }
     HIP_OK(hipEventRecord(r.copied[slot], r.copy_stream));
     HIP_OK(hipStreamWaitEvent(r.stream, r.copied[slot], 0));
-    HIP_OK(hipEventRecord(r.time_events[2 * c], r.stream));
-    if (enqueue(r.d_images[slot], m, ncls, classes ? r.d_classes + base : nullptr, want_scores ? r.d_scores + (size_t)base * 64 : nullptr,
-                r.d_words + base, r.stream))
-      return -1;
-    HIP_OK(hipEventRecord(r.time_events[2 * c + 1], r.stream));
-    HIP_OK(hipEventRecord(r.consumed[slot], r.stream));
+    if (consume(c, base, m, slot)) return -1;
+    // (with reuse_slots the consumer's stages read `packed`; without, only the strip kernel reads d_file[slot])
+    HIP_OK(hipEventRecord(r.consumed[slot], reuse_slots ? r.stream : r.copy_stream));
   }
-  (void)isz;
+  return 0;
+}
+
+// images [0, n) of an open file -> any of classes / scores / words (host arrays).  Same contract as
+// infer_host; the timed region is again the compute stages alone.
+int infer_file(const ImageFile &f, int n, int ncls, int32_t *classes, int16_t *scores, uint64_t *words, float *usec) {
+  Runtime &r = rt();
+  if (!ready()) return -1;
+  if (ncls < 1 || ncls > 64) return fail("number_class must be in 1..64");
+  if (usec) *usec = 0.f;
+  if (n <= 0) return 0;
+  const int chunk = n < kHostChunk ? n : kHostChunk;
+  const int nchunks = (n + chunk - 1) / chunk;
+  if (reserve(chunk) || reserve_host(chunk, (size_t)n)) return -1;
+  while ((int)r.time_events.size() < 2 * nchunks) {
+    hipEvent_t e;
+    HIP_OK(hipEventCreate(&e));
+    r.time_events.push_back(e);
+  }
+  const bool want_scores = scores && r.spec.is_cnv;
+  const int rc = stream_file(
+      f, n, true, [&](int, int slot) { return r.d_images[slot]; },
+      [&](int c, int base, int m, int slot) {
+        HIP_OK(hipEventRecord(r.time_events[2 * c], r.stream));
+        if (enqueue(r.d_images[slot], m, ncls, classes ? r.d_classes + base : nullptr, want_scores ? r.d_scores + (size_t)base * 64 : nullptr,
+                    r.d_words + base, r.stream))
+          return -1;
+        HIP_OK(hipEventRecord(r.time_events[2 * c + 1], r.stream));
+        return 0;
+      });
+  if (rc) return -1;
   if (classes) HIP_OK(hipMemcpyAsync(classes, r.d_classes, (size_t)n * 4, hipMemcpyDeviceToHost, r.stream));
   if (want_scores) HIP_OK(hipMemcpyAsync(scores, r.d_scores, (size_t)n * 128, hipMemcpyDeviceToHost, r.stream));
   if (words && !r.spec.is_cnv) HIP_OK(hipMemcpyAsync(words, r.d_words, (size_t)n * 8, hipMemcpyDeviceToHost, r.stream));
@@ -510,6 +498,18 @@ int infer_file(const ImageFile &f, int n, int ncls, int32_t *classes, int16_t *s
     total_ms += ms;
   }
   if (usec) *usec = (float)(total_ms * 1000.0 / n);
+  return 0;
+}
+
+// all images of a file, packed, resident in HBM at r.d_all (fault campaigns classify them in runs)
+int load_file_resident(const ImageFile &f, int n) {
+  Runtime &r = rt();
+  const size_t isz = (size_t)r.spec.image_bytes();
+  if (bind_device() || grow(r.d_all, r.all_cap, (size_t)n * isz + 256)) return -1;
+  if (stream_file(
+          f, n, false, [&](int c, int) { return r.d_all + (size_t)c * kHostChunk * isz; }, [&](int, int, int, int) { return 0; }))
+    return -1;
+  HIP_OK(hipStreamSynchronize(r.copy_stream));
   return 0;
 }
 
@@ -637,49 +637,77 @@ int *inference_multiple_with_faults(const char *path, int number_class, int *ima
     fail("fault injection needs the parameter files (load_parameters), not an imported blob");
     return nullptr;
   }
-  std::vector<uint8_t> imgs;
-  const int n = read_images(path, imgs);
-  if (n < 0) return nullptr;
+  ImageFile f;
+  if (open_image_file(path, f)) return nullptr;
+  const int n = (int)f.n;
   // The reference classifies image by image and injects each fault just before the image it was
-  // drawn for (faults.h:115-148).  Same result, fewer launches: classify the run of images between
-  // two fault times as one batch, then patch the affected rows in HBM.
+  // drawn for (faults.h:115-148).  Same result, fewer launches: the images go to HBM once, the run
+  // of images between two fault times is classified as one batch, and a fault patches the one
+  // affected row of the blob in HBM -- all of it queued on one stream, one wait at the end.
   r.last_faults = plan_faults(r.spec, r.fault_seed, n, flip_count, word_size, target, target_layers, num_targets);
   int *result = new (std::nothrow) int[(size_t)(n > 0 ? n : 1)];
   if (!result) { fail("out of memory"); return nullptr; }
-  const size_t isz = (size_t)r.spec.image_bytes();
-  double total_us = 0.0;
-  size_t k = 0;
-  int start = 0;
-  while (start < n) {
-    while (k < r.last_faults.size() && r.last_faults[k].image <= start) {
-      const Fault &f = r.last_faults[k++];
-      const int row = apply_fault(r.spec, r.raw, f);
-      if (row < 0) continue;
-      size_t off = 0, bytes = 0;
-      repack_row(r.spec, r.raw, f.layer, row, r.blob, &off, &bytes);
-      if (hipMemcpy(static_cast<uint8_t *>(r.d_blob) + off, r.blob.data() + off, bytes, hipMemcpyHostToDevice) != hipSuccess) {
-        fail("hipMemcpy of a patched parameter row failed");
-        delete[] result;
-        return nullptr;
+  auto run = [&]() -> int {
+    if (n == 0) return 0;
+    const size_t isz = (size_t)r.spec.image_bytes();
+    if (load_file_resident(f, n)) return -1;
+    if (reserve(n) || reserve_host(1, (size_t)n)) return -1;
+    std::vector<std::vector<uint8_t>> patches;  // row images must outlive their asynchronous upload
+    patches.reserve(r.last_faults.size());
+    size_t k = 0, ev = 0;
+    int start = 0;
+    while (start < n) {
+      while (k < r.last_faults.size() && r.last_faults[k].image <= start) {
+        const Fault &flt = r.last_faults[k++];
+        const int row = apply_fault(r.spec, r.raw, flt);
+        if (row < 0) continue;
+        size_t off = 0, bytes = 0;
+        repack_row(r.spec, r.raw, flt.layer, row, r.blob, &off, &bytes);
+        patches.emplace_back(r.blob.begin() + off, r.blob.begin() + off + bytes);
+        HIP_OK(hipMemcpyAsync(static_cast<uint8_t *>(r.d_blob) + off, patches.back().data(), bytes, hipMemcpyHostToDevice, r.stream));
       }
+      const int end = (k < r.last_faults.size()) ? r.last_faults[k].image : n;
+      for (int base = start; base < end; base += kMaxChunk) {
+        const int m = (end - base < kMaxChunk) ? end - base : kMaxChunk;
+        if (r.time_events.size() < ev + 2) {
+          hipEvent_t e0, e1;
+          HIP_OK(hipEventCreate(&e0));
+          HIP_OK(hipEventCreate(&e1));
+          r.time_events.push_back(e0);
+          r.time_events.push_back(e1);
+        }
+        HIP_OK(hipEventRecord(r.time_events[ev], r.stream));
+        if (enqueue(r.d_all + (size_t)base * isz, m, number_class, r.d_classes + base, nullptr, r.d_words + base, r.stream)) return -1;
+        HIP_OK(hipEventRecord(r.time_events[ev + 1], r.stream));
+        ev += 2;
+      }
+      start = end;
     }
-    const int end = (k < r.last_faults.size()) ? r.last_faults[k].image : n;
-    const int m = end - start;
-    float usec = 0.f;
-    int rc;
+    std::vector<uint64_t> w;
     if (r.spec.is_cnv) {
-      rc = infer_host(imgs.data() + (size_t)start * isz, m, number_class, result + start, nullptr, nullptr, &usec);
-    } else {
-      std::vector<uint64_t> w((size_t)m);
-      rc = infer_host(imgs.data() + (size_t)start * isz, m, number_class, nullptr, nullptr, w.data(), &usec);
-      for (int i = 0; rc == 0 && i < m; i++) result[start + i] = lfc_class_batched(w[i], number_class);
+      HIP_OK(hipMemcpyAsync(result, r.d_classes, (size_t)n * 4, hipMemcpyDeviceToHost, r.stream));
+    } else {  // host decode, like the batched LFC entry point
+      w.resize((size_t)n);
+      HIP_OK(hipMemcpyAsync(w.data(), r.d_words, (size_t)n * 8, hipMemcpyDeviceToHost, r.stream));
     }
-    if (rc) { delete[] result; return nullptr; }
-    total_us += (double)usec * m;
-    start = end;
+    HIP_OK(hipStreamSynchronize(r.stream));
+    for (int i = 0; !r.spec.is_cnv && i < n; i++) result[i] = lfc_class_batched(w[i], number_class);
+    double ms_total = 0.0;
+    for (size_t e = 0; e < ev; e += 2) {
+      float ms = 0.f;
+      HIP_OK(hipEventElapsedTime(&ms, r.time_events[e], r.time_events[e + 1]));
+      ms_total += ms;
+    }
+    return (int)(ms_total * 1000.0 + 0.5);  // total device microseconds of the stages
+  };
+  const int total_us = run();
+  if (total_us < 0) {
+    (void)hipStreamSynchronize(r.stream);  // nothing may still read the patch buffers
+    delete[] result;
+    return nullptr;
   }
-  const float usec = n > 0 ? (float)(total_us / n) : 0.f;
-  std::printf("Inference took %.0f microseconds, %g usec per image\n", total_us, usec);
+  const float usec = n > 0 ? (float)total_us / (float)n : 0.f;
+  std::printf("Inference took %.0f microseconds, %g usec per image\n", (double)total_us, usec);
   std::printf("Classification rate: %g images per second\n", 1000000.0 / usec);
   if (image_number) *image_number = n;
   if (usecPerImage) *usecPerImage = usec;
