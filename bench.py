@@ -292,6 +292,19 @@ def main():
         out["cpu_baseline"] = {"value": round(sample / dt, 1), "unit": "images/s", "cores": cores, "kind": "port",
                                "sample": "first %d images of the GPU batch, %.1f s, popcount+OpenMP restatement "
                                          "(oracle/), classes equal to the GPU's on all of them" % (sample, dt)}
+        # the faithful form (one thread, the scalar structure of the reference's HLS C simulation: the analogue
+        # of its published 2.39 img/s CNV / 58 img/s LFC on one ARM core), a few images
+        k = 3 if is_cnv else 50
+        t1 = time.perf_counter()
+        for i in range(k):
+            if is_cnv:
+                s = o.scores_ref(host[i])
+                if int(ol.decode_cnv_batched(s, ncls)) != int(got[i]):
+                    sys.exit("PARITY FAILURE: GPU class differs from the faithful scalar restatement")
+            else:
+                o.word_ref(host[i])
+        out["cpu_baseline"]["faithful_single_thread"] = {"value": round(k / (time.perf_counter() - t1), 2), "unit": "images/s",
+                                                          "cores": 1, "sample": "%d images" % k}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
