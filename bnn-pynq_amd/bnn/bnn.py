@@ -82,12 +82,23 @@ def _open_library(dllname):
     return _libraries[dllname]
 
 
+def _param_name(network, dataset_dir):
+    """directory name holding `network`'s parameters: the hardened variants (-TMR, -interleaved,
+    -resilient-interleaved) ship byte-identical copies of their base network's files in the
+    reference; this package keeps one copy and resolves the variant to its base when absent"""
+    names = os.listdir(dataset_dir)
+    if network in names:
+        return network
+    base = network.split("-")[0]
+    return base if base != network and base in names else None
+
+
 def available_params(network):
     """datasets for which a parameter set of `network` is installed"""
     found = []
     for dataset in os.listdir(BNN_PARAM_DIR):
         dpath = os.path.join(BNN_PARAM_DIR, dataset)
-        if os.path.isdir(dpath) and network in os.listdir(dpath):
+        if os.path.isdir(dpath) and _param_name(network, dpath):
             found.append(dataset)
     return found
 
@@ -114,6 +125,10 @@ class PynqBNN:
     def load_parameters(self, params):
         if not os.path.isabs(params):
             params = os.path.join(BNN_PARAM_DIR, params)
+            if not os.path.isdir(params) and os.path.isdir(os.path.dirname(params)):
+                name = _param_name(os.path.basename(params), os.path.dirname(params))
+                if name:
+                    params = os.path.join(os.path.dirname(params), name)
         if os.path.isdir(params):
             self.interface.load_parameters(params.encode())
             with open(os.path.join(params, "classes.txt")) as f:

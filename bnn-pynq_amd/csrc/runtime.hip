@@ -41,6 +41,9 @@
 #ifndef BNN_NETWORK
 #error "compile with -DBNN_NETWORK=NET_CNVW1A1 (or another bnn::NetId)"
 #endif
+// BNN_VARIANT: the library is built under the name of one of the fork's hardened overlays
+// (cnvW1A1-TMR, ...-interleaved, ...): same compute as BNN_NETWORK, same parameter files; their
+// fault model (replicated / bit-interleaved parameter memories) is not modelled.
 
 namespace bnn {
 namespace {
@@ -632,6 +635,12 @@ int *inference_multiple_with_faults(const char *path, int number_class, int *ima
                                     int target, int *target_layers, unsigned int num_targets) {
   Runtime &r = rt();
   if (flip_count == 0) return inference_multiple(path, number_class, image_number, usecPerImage, 0);
+#ifdef BNN_VARIANT
+  // TMRBinaryWeights / the interleaved memories live in the un-vendored finn-hlslib fork: their voting
+  // and de-interleaving are not restated here, so a fault campaign would not mean what the caller expects
+  fail("fault injection is not modelled for " BNN_VARIANT " (replicated / interleaved parameter memories); use the base network");
+  return nullptr;
+#endif
   if (!ready()) return nullptr;
   if (r.raw.empty()) {
     fail("fault injection needs the parameter files (load_parameters), not an imported blob");
@@ -718,7 +727,13 @@ void free_results(int *result) { delete[] result; }
 
 void deinit(void) { free_workspace(); }
 
-const char *bnn_mi355x_network(void) { return rt().spec.name; }
+const char *bnn_mi355x_network(void) {
+#ifdef BNN_VARIANT
+  return BNN_VARIANT;
+#else
+  return rt().spec.name;
+#endif
+}
 int bnn_mi355x_image_bytes(void) { return rt().spec.image_bytes(); }
 const char *bnn_mi355x_last_error(void) { return rt().err.c_str(); }
 

@@ -11,6 +11,10 @@ import gpu_lib as gl
 
 HEADER = os.path.join(gl.ROOT, "include", "bnn_mi355x.h")
 NETWORKS = ["cnvW1A1", "cnvW1A2", "cnvW2A2", "lfcW1A1", "lfcW1A2"]
+# the fork's hardened overlays (bnn.py:41-53): same compute, built under their own names
+VARIANTS = ["cnvW1A1-interleaved", "cnvW1A1-resilient-interleaved", "cnvW1A1-TMR", "cnvW1A2-interleaved",
+            "cnvW1A2-resilient-interleaved", "cnvW2A2-interleaved", "cnvW2A2-resilient-interleaved", "cnvW2A2-TMR",
+            "lfcW1A2-interleaved"]
 
 
 def declared_symbols():
@@ -27,7 +31,7 @@ def test_header_declares_the_reference_cdef():
     assert sorted(gl.LEGACY + gl.EXT) == d
 
 
-@pytest.mark.parametrize("network", NETWORKS)
+@pytest.mark.parametrize("network", NETWORKS + VARIANTS)
 @pytest.mark.parametrize("runtime", ["python_sw", "python_hw"])
 def test_library_exports(network, runtime):
     path = gl.lib_path(network, runtime)

@@ -367,6 +367,38 @@ def test_file_abi_streams_multi_chunk_files(network, dataset, n, tmp_path):
     L.free_results(p)
 
 
+@pytest.mark.parametrize("variant,dataset", [("cnvW1A1-TMR", "cifar10"), ("cnvW2A2-resilient-interleaved", "cifar10"),
+                                             ("lfcW1A2-interleaved", "mnist")])
+def test_hardened_variants_are_the_base_network(variant, dataset, tmp_path):
+    """cnvW1A1-TMR & co (bnn.py:41-53): same classes as the base network through the Python API; fault
+    injection is refused for them (their memory organisation is not modelled), not silently approximated"""
+    import sys
+    sys.path.insert(0, os.path.join(gl.ROOT, "bnn-pynq_amd"))
+    import bnn
+    base = variant.split("-")[0]
+    cnv = base.startswith("cnv")
+    imgs = rand_images(base, 300, 5)
+    path = tmp_path / "in.bin"
+    with open(path, "wb") as f:
+        if cnv:
+            rec = np.zeros((300, 3073), np.uint8)
+            rec[:, 1:] = imgs
+            f.write(rec.tobytes())
+        else:
+            f.write((0x803).to_bytes(4, "big") + (300).to_bytes(4, "big") + (28).to_bytes(4, "big") * 2 + imgs.tobytes())
+    Clf = bnn.CnvClassifier if cnv else bnn.LfcClassifier
+    v = Clf(variant, dataset, bnn.RUNTIME_SW)
+    got = v.classify_cifars(str(path)) if cnv else v.classify_mnists(str(path))
+    assert list(got) == oracle(base, dataset).classes_batched(imgs, len(v.classes)).tolist()
+    assert v.bnn.interface.bnn_mi355x_network().decode() == variant
+    n = C.c_int(0)
+    p = v.bnn.interface.inference_multiple_with_faults(str(path).encode(), 10, C.byref(n), None, 5, 1, -1, None, 0)
+    assert not p and b"not modelled" in v.bnn.interface.bnn_mi355x_last_error()
+    p = v.bnn.interface.inference_multiple_with_faults(str(path).encode(), 10, C.byref(n), None, 0, 1, -1, None, 0)   # no flips: plain inference
+    assert p and n.value == 300
+    v.bnn.interface.free_results(p)
+
+
 def test_layer0_integer_pipe_kernel_agrees():
     """BNN_MI355X_L0=valu selects k_conv0 (v_dot4c) instead of the MFMA first layer: same bits"""
     import subprocess

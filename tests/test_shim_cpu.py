@@ -95,3 +95,12 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(mod, "_libraries", {})
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         bnn.PynqBNN(bnn.RUNTIME_SW, bnn.NETWORK_LFCW1A1)
+
+
+def test_variant_constants_resolve_to_base_parameters():
+    """the hardened overlays' names (bnn.py:41-53) find the base network's (byte-identical) parameter files"""
+    import bnn
+    assert bnn.NETWORK_CNVW1A1_TMR == "cnvW1A1-TMR" and bnn.NETWORK_LFCW1A2_INTERLEAVED == "lfcW1A2-interleaved"
+    assert set(bnn.available_params(bnn.NETWORK_CNVW1A1_TMR)) == set(bnn.available_params(bnn.NETWORK_CNVW1A1))
+    assert "mnist" in bnn.available_params(bnn.NETWORK_LFCW1A2_INTERLEAVED)
+    assert bnn.available_params("cnvW9A9-TMR") == []
