@@ -881,9 +881,13 @@ __global__ __launch_bounds__(kBlock) void k_lfc_decode(const uint64_t *__restric
 // so that a lane writes whole output words and reads its window once; otherwise one (parallelism first)
 inline int gpb_for(long long items, int groups) { return (items + kBlock - 1) / kBlock >= 2048 ? groups : 1; }
 
-// small batches: 8 neurons per block instead of 32 while the 32-neuron grid would not even give
-// every SIMD of the chip two waves (256 CUs x 4 SIMDs x 2 / 4 waves per block)
-inline bool narrow_for(long long items, int groups32) { return ((items + kBlock - 1) / kBlock) * groups32 < 512; }
+// small batches: 8 neurons per block instead of 32 while the 32-neuron grid is short of blocks (four
+// times as many, four times shorter blocks balance better over the 1024 SIMDs)
+inline bool narrow_for(long long items, int groups32, long long limit) { return ((items + kBlock - 1) / kBlock) * groups32 < limit; }
+// measured (tools/batch_sweep.py): the conv stages gain from the 8-neuron form up to ~8192 blocks of the
+// 32-neuron grid (1024 images +10 %, 4096 +9 %); the FC stacks of the LFC nets (16-word inputs, 1024
+// neurons) lose beyond 512
+constexpr long long kNarrowLimitCnv = 8192, kNarrowLimitLfc = 512;
 
 inline dim3 grid_for(long long items, int groups) {  // matches map_block()
   const long long item_blocks = (items + kBlock - 1) / kBlock;
@@ -899,7 +903,7 @@ inline dim3 grid_for(long long items, int groups) {  // matches map_block()
 #define BNN_STAGE(kern32, kern8, items, groups32, in, out, rows)                                                                   \
   do {                                                                                                                             \
     const long long it_ = (items);                                                                                                 \
-    if (narrow_for(it_, (groups32))) BNN_LAUNCH(kern8, grid_for(it_, (groups32) * 4), s, in, out, rows, (int)it_, (groups32) * 4, 1); \
+    if (narrow_for(it_, (groups32), narrow_limit)) BNN_LAUNCH(kern8, grid_for(it_, (groups32) * 4), s, in, out, rows, (int)it_, (groups32) * 4, 1); \
     else BNN_LAUNCH(kern32, grid_for(it_, (groups32) / gpb_for(it_, (groups32))), s, in, out, rows, (int)it_, (groups32), gpb_for(it_, (groups32))); \
   } while (0)
 // stage boundary: with profiling on, an event separates consecutive stages
@@ -910,7 +914,7 @@ inline dim3 grid_for(long long items, int groups) {  // matches map_block()
 
 template <int ARITH, bool OUT2>
 void run_cnv_t(const CnvLaunch &a) {
-  const long long n = a.n;
+  const long long n = a.n, narrow_limit = kNarrowLimitCnv;
   uint32_t *A = reinterpret_cast<uint32_t *>(a.buf0), *B = reinterpret_cast<uint32_t *>(a.buf1);
   const uint64_t *A64 = reinterpret_cast<const uint64_t *>(a.buf0), *B64 = reinterpret_cast<const uint64_t *>(a.buf1);
   hipStream_t s = a.stream;
@@ -1003,7 +1007,7 @@ hipError_t run_cnv(NetId net, const CnvLaunch &a) {
 
 hipError_t run_lfc(NetId net, const LfcLaunch &a) {
   if (a.n <= 0) return hipSuccess;
-  const long long n = a.n;
+  const long long n = a.n, narrow_limit = kNarrowLimitLfc;
   uint32_t *A = reinterpret_cast<uint32_t *>(a.buf0), *B = reinterpret_cast<uint32_t *>(a.buf1);
   uint64_t *A64 = reinterpret_cast<uint64_t *>(a.buf0), *B64 = reinterpret_cast<uint64_t *>(a.buf1);
   hipStream_t s = a.stream;

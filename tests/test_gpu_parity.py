@@ -174,8 +174,10 @@ def test_full_size_batch_properties():
 
 @pytest.mark.parametrize("network", ["cnvW1A1", "cnvW1A2", "cnvW2A2"])
 def test_large_batch_takes_the_wide_paths(network):
-    """>= 58 255 images: every stage switches to 'all neuron groups in one block' (gpb_for in
-    kernels.hip); seeded oracle sample + the small-batch result of the same images must agree"""
+    """60 000 images through the host-buffer entry point = chunks of 32 768: the conv stages run in their
+    'all neuron groups in one block' form (gpb_for in kernels.hip), the 500-image call below in the 8-neuron
+    form; both must agree with each other and with a seeded oracle sample (the full-size device-API test
+    covers the wide form of the remaining stages)"""
     n = 60000
     imgs = rand_images(network, n, 21)
     net = gpu_net(network, "cifar10")
