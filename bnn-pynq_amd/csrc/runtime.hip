@@ -346,7 +346,7 @@ int open_image_file(const char *path, ImageFile &f) {
   struct stat st;
   if (f.fd < 0 || ::fstat(f.fd, &st) != 0) return fail(std::string("Could not open file ") + (path ? path : ""));
   const size_t size = (size_t)st.st_size;
-  if (r.spec.is_cnv) {  // whole records only, like the fread loop of read_cifar_file
+  if (r.spec.is_cnv) {  // whole records only, a trailing partial record is ignored (the reference reads record by record)
     f.rec = 3073; f.skip = 1; f.first = 0;
     f.n = size / 3073;
   } else {
