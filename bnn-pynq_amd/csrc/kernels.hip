@@ -41,7 +41,7 @@ typedef const uint32_t __attribute__((address_space(4))) *kptr32;
 typedef const uint64_t __attribute__((address_space(4))) *kptr64;
 
 constexpr int kBlock = 256;
-constexpr int kLfcFusedMax = 4096;  // images: up to here the one-launch LFC kernel beats the six staged ones (tools/batch_sweep.py)
+constexpr int kLfcFusedMax = 4096, kLfcFusedMaxA2 = 2048;  // images: up to here the one-launch LFC kernels beat the six staged ones (tools/batch_sweep.py)
 
 // Block -> (work-item block, neuron group), XCD-aware.  The `groups` blocks that evaluate
 // different 32-neuron groups for the SAME 256 work items read the same input windows and write
@@ -788,6 +788,94 @@ __global__ __launch_bounds__(kBlock) void k_lfc_binarize(const uint8_t *__restri
 // v_cmp writes the 64-bit lane mask, which is exactly the next layer's input word.  Three
 // __syncthreads() separate the layers.  Used for small batches, where the throughput kernels
 // (one lane per IMAGE) would leave the chip empty: 1 image 44 us -> see profiles/.
+// The same one-launch form for lfcW1A2 (2-bit activations): a layer's output is two words per wave,
+// the sign plane (neither threshold exceeded: -1) and the non-zero plane (both or neither: +-1), formed
+// from the two ballots of the wave; layers 1..3 use the ternary inner product m = popc(za & (sa ^ w)),
+// fire_i  <=>  t_i < nz - 2m  (nz = non-zero inputs of the image, the same for every neuron).
+template <int KW>
+__device__ __forceinline__ void lfc_load_row2(const uint32_t *__restrict__ rows, int n, uint64_t (&w)[KW], int &t0, int &t1) {
+  constexpr int ROW_DW = 2 + 2 * KW;
+  const uint32_t *__restrict__ r = rows + (size_t)n * ROW_DW;
+  const uint64_t *__restrict__ p = reinterpret_cast<const uint64_t *>(r + 2);
+  t0 = (int)r[0];
+  t1 = (int)r[1];
+#pragma unroll
+  for (int k = 0; k < KW; k++) w[k] = p[k];
+}
+// 2m - nz of one neuron against one image's (sign, non-zero) planes
+template <int KW>
+__device__ __forceinline__ int lfc_q_tb(const uint64_t (&w)[KW], const uint64_t *sa, const uint64_t *za) {
+  int m = 0, nz = 0;
+#pragma unroll
+  for (int k = 0; k < KW; k++) {
+    const uint64_t z = za[k];
+    m += pc64(z & (sa[k] ^ w[k]));
+    nz += pc64(z);
+  }
+  return 2 * m - nz;
+}
+
+template <int IPB>
+__global__ __launch_bounds__(1024) void k_lfc_fused_a2(const uint8_t *__restrict__ imgs, uint64_t *__restrict__ words,
+                                                        int32_t *__restrict__ classes, const uint32_t *__restrict__ r0,
+                                                        const uint32_t *__restrict__ r1, const uint32_t *__restrict__ r2,
+                                                        const uint32_t *__restrict__ r3, int n_images, int number_class) {
+  __shared__ uint64_t in0[IPB][16];        // binarised input
+  __shared__ uint64_t sg[2][IPB][16], nzp[2][IPB][16];  // ping-pong (sign, non-zero) planes
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, img0 = blockIdx.x * IPB;
+  uint64_t w0[13], w1[16], w2[16], w3[16];
+  int a0, b0, a1, b1, a2, b2, a3 = 0, b3 = 0;
+  lfc_load_row2<13>(r0, t, w0, a0, b0);
+#pragma unroll
+  for (int i = 0; i < IPB; i++) {
+    const int img = img0 + i < n_images ? img0 + i : n_images - 1;
+    const uint8_t px = (t < 784) ? imgs[(size_t)img * 784 + t] : 0;
+    const uint64_t word = __ballot(px >= 128);
+    if (lane == 0) in0[i][wave] = word;
+  }
+  lfc_load_row2<16>(r1, t, w1, a1, b1);
+  __syncthreads();
+  // layer 0: XNOR inner product, two thresholds (pre-transformed: fire_i <=> m < t_i)
+#pragma unroll
+  for (int i = 0; i < IPB; i++) {
+    int m = 0;
+#pragma unroll
+    for (int k = 0; k < 13; k++) m += pc64(w0[k] ^ in0[i][k]);
+    const uint64_t f0 = __ballot(m < a0), f1 = __ballot(m < b0);
+    if (lane == 0) { sg[0][i][wave] = ~(f0 | f1); nzp[0][i][wave] = ~(f0 ^ f1); }
+  }
+  lfc_load_row2<16>(r2, t, w2, a2, b2);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < IPB; i++) {
+    const int q = lfc_q_tb<16>(w1, sg[0][i], nzp[0][i]);
+    const uint64_t f0 = __ballot(q + a1 < 0), f1 = __ballot(q + b1 < 0);
+    if (lane == 0) { sg[1][i][wave] = ~(f0 | f1); nzp[1][i][wave] = ~(f0 ^ f1); }
+  }
+  if (wave == 0) lfc_load_row2<16>(r3, lane, w3, a3, b3);
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < IPB; i++) {
+    const int q = lfc_q_tb<16>(w2, sg[1][i], nzp[1][i]);
+    const uint64_t f0 = __ballot(q + a2 < 0), f1 = __ballot(q + b2 < 0);
+    if (lane == 0) { sg[0][i][wave] = ~(f0 | f1); nzp[0][i][wave] = ~(f0 ^ f1); }
+  }
+  __syncthreads();
+  if (wave == 0) {  // last layer: 64 neurons, one threshold, one wave
+#pragma unroll
+    for (int i = 0; i < IPB; i++) {
+      const uint64_t word = __ballot(lfc_q_tb<16>(w3, sg[0][i], nzp[0][i]) + a3 < 0);
+      if (lane == 0 && img0 + i < n_images) {
+        words[img0 + i] = word;
+        if (classes) {
+          const uint64_t w = word & (~0ull >> (64 - number_class));
+          classes[img0 + i] = w ? 63 - __builtin_clzll(w) : 0;
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 template <int KW>
 __device__ __forceinline__ void lfc_load_row(const uint32_t *__restrict__ rows, int n, uint64_t (&w)[KW], int &t) {
@@ -1011,18 +1099,27 @@ hipError_t run_lfc(NetId net, const LfcLaunch &a) {
   uint32_t *A = reinterpret_cast<uint32_t *>(a.buf0), *B = reinterpret_cast<uint32_t *>(a.buf1);
   uint64_t *A64 = reinterpret_cast<uint64_t *>(a.buf0), *B64 = reinterpret_cast<uint64_t *>(a.buf1);
   hipStream_t s = a.stream;
-  if (net == NET_LFCW1A1 && n <= kLfcFusedMax && !a.events && a.last_stage >= kLfcStages - 1) {
+  if (n <= (net == NET_LFCW1A1 ? kLfcFusedMax : kLfcFusedMaxA2) && !a.events && a.last_stage >= kLfcStages - 1) {
     // small batch: the one-launch form, a block per group of IPB images (no per-stage events: there are no
     // stages).  A block costs ~8 us + ~1.6 us per further image whatever the batch, so the group is the
     // smallest that still fits the batch in one round of 256 blocks (profiles/r01_lfc_forms.txt).
     const int ipb = n <= 256 ? 1 : n <= 512 ? 2 : n <= 1024 ? 4 : 8;
     const dim3 g((unsigned)((n + ipb - 1) / ipb)), b(1024);
-#define BNN_FUSED(I) \
-  hipLaunchKernelGGL(k_lfc_fused<I>, g, b, 0, s, a.images, a.words, a.classes, a.rows[0], a.rows[1], a.rows[2], a.rows[3], (int)n, a.number_class)
-    if (ipb == 1) BNN_FUSED(1);
-    else if (ipb == 2) BNN_FUSED(2);
-    else if (ipb == 4) BNN_FUSED(4);
-    else BNN_FUSED(8);
+#define BNN_FUSED(K, I) \
+  hipLaunchKernelGGL(K<I>, g, b, 0, s, a.images, a.words, a.classes, a.rows[0], a.rows[1], a.rows[2], a.rows[3], (int)n, a.number_class)
+    if (net == NET_LFCW1A1) {
+      if (ipb == 1) BNN_FUSED(k_lfc_fused, 1);
+      else if (ipb == 2) BNN_FUSED(k_lfc_fused, 2);
+      else if (ipb == 4) BNN_FUSED(k_lfc_fused, 4);
+      else BNN_FUSED(k_lfc_fused, 8);
+    } else if (net == NET_LFCW1A2) {
+      if (ipb == 1) BNN_FUSED(k_lfc_fused_a2, 1);
+      else if (ipb == 2) BNN_FUSED(k_lfc_fused_a2, 2);
+      else if (ipb == 4) BNN_FUSED(k_lfc_fused_a2, 4);
+      else BNN_FUSED(k_lfc_fused_a2, 8);
+    } else {
+      return hipErrorInvalidValue;
+    }
 #undef BNN_FUSED
     return hipGetLastError();
   }

@@ -59,6 +59,7 @@ struct Runtime {
   RawParams raw;  // the reference-layout memories (empty when the blob was imported)
   std::vector<uint8_t> blob;
   void *d_blob = nullptr;
+  size_t d_blob_bytes = 0;
   uint64_t fault_seed = 0;  // 0: std::random_device, like the reference
   int debug_last_stage = -1;  // >= 0: stop after this stage (bnn_mi355x_debug_stage_output)
   std::vector<Fault> last_faults;
@@ -132,8 +133,12 @@ int bind_device() {
 int upload_blob() {
   Runtime &r = rt();
   if (bind_device()) return -1;
-  if (r.d_blob) { HIP_OK(hipFree(r.d_blob)); r.d_blob = nullptr; }
-  HIP_OK(hipMalloc(&r.d_blob, r.blob.size()));
+  if (r.d_blob && r.d_blob_bytes != r.blob.size()) { HIP_OK(hipFree(r.d_blob)); r.d_blob = nullptr; }
+  if (!r.d_blob) {
+    HIP_OK(hipMalloc(&r.d_blob, r.blob.size()));
+    r.d_blob_bytes = r.blob.size();
+  }
+  HIP_OK(hipDeviceSynchronize());  // a reload (fault campaigns reload per run): nothing may still read the old rows
   HIP_OK(hipMemcpy(r.d_blob, r.blob.data(), r.blob.size(), hipMemcpyHostToDevice));
   const PackedHeader *h = reinterpret_cast<const PackedHeader *>(r.blob.data());
   for (int l = 0; l < r.spec.nlayers; l++)

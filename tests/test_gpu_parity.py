@@ -249,15 +249,17 @@ def test_device_api_crosses_the_chunk_boundary():
     assert (cls2 == cls[131072:]).all()
 
 
-@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 128, 129, 256, 257, 511, 512, 513, 1023, 1025, 2047, 4093, 4096, 4097])
-def test_lfc_small_batches_take_the_fused_kernel(n):
-    """<= 4096 images: lfcW1A1 runs as one launch, a block per group of 1/2/4/8 images (k_lfc_fused<IPB>);
-    sizes either side of every policy edge, ragged last groups included; 4097 takes the staged path"""
+@pytest.mark.parametrize("network", ["lfcW1A1", "lfcW1A2"])
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 128, 129, 256, 257, 511, 512, 513, 1023, 1025, 2047, 2048, 2049, 4093, 4096, 4097])
+def test_lfc_small_batches_take_the_fused_kernel(network, n):
+    """<= 4096 (lfcW1A2: 2048) images: the LFC nets run as one launch, a block per group of 1/2/4/8 images (k_lfc_fused<IPB>,
+    k_lfc_fused_a2<IPB>); sizes either side of every policy edge, ragged last groups included; 4097 takes
+    the staged path"""
     import torch
-    net = gpu_net("lfcW1A1", "mnist")
-    o = oracle("lfcW1A1", "mnist")
+    net = gpu_net(network, "mnist")
+    o = oracle(network, "mnist")
     for kind in ("uniform", "sparse"):
-        imgs = rand_images("lfcW1A1", n, 30 + n, kind)
+        imgs = rand_images(network, n, 30 + n, kind)
         assert (net.raw(imgs) == o.words_fast(imgs)).all()
         d = torch.from_numpy(imgs).cuda()
         cls = torch.zeros(n, dtype=torch.int32, device="cuda")
