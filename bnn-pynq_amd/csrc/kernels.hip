@@ -756,6 +756,46 @@ __global__ __launch_bounds__(kBlock) void k_fclast(const uint64_t *__restrict__ 
   if (classes) classes[item] = best;
 }
 
+// The same layer for small batches: one WAVE per image, lane = neuron (the layer has exactly 64).  With a
+// lane per image a single image is a serial chain of 64 neurons x 8 words on one lane (13 us); here it is
+// 8 words per lane and a wave reduction for the decode.  key = score * 64 + (63 - neuron) orders by score,
+// then by lowest index; scores <= 0 never beat the initial (class 0, value 0) of the reference's loop.
+template <int ARITH, int KW>
+__global__ __launch_bounds__(kBlock) void k_fclast_wave(const uint64_t *__restrict__ in, int16_t *__restrict__ scores,
+                                                         int32_t *__restrict__ classes, const uint32_t *__restrict__ rows,
+                                                         int n_items, int number_class) {
+  constexpr int PL = planes_in<ARITH>(), WPL = wplanes<ARITH>();
+  constexpr int ROW_DW = 2 + 2 * KW * WPL;
+  const int lane = threadIdx.x & 63, item = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  if (item >= n_items) return;  // wave-uniform
+  const uint64_t *__restrict__ base = in + (size_t)item * KW * PL;
+  const uint64_t *__restrict__ rw = reinterpret_cast<const uint64_t *>(rows + (size_t)lane * ROW_DW + 2);
+  int m = 0, z = 0, nzt = 0;
+#pragma unroll
+  for (int k = 0; k < KW; k++) {
+    const uint64_t as = base[k * PL], az = (PL == 2) ? base[k * PL + 1] : 0;
+    if constexpr (ARITH == AR_XNOR) {
+      m += pc64(rw[k] ^ as);
+    } else if constexpr (ARITH == AR_TB) {
+      m += pc64(az & (as ^ rw[k]));
+      nzt += pc64(az);
+    } else {
+      const uint64_t zz = az & rw[k * 2 + 1];
+      z += pc64(zz);
+      m += pc64(zz & (as ^ rw[k * 2]));
+    }
+  }
+  int sc = (ARITH == AR_XNOR) ? (KW * 64 - m) : finish<ARITH>(m, z, nzt);
+  sc = (int)(int16_t)sc;  // 16-bit output word read back as ap_int<16>
+  if (scores) scores[(size_t)item * 64 + lane] = (int16_t)sc;
+  if (classes) {
+    int key = (lane < number_class && sc > 0) ? sc * 64 + (63 - lane) : -1;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) key = max(key, __shfl_xor(key, off, 64));
+    if (lane == 0) classes[item] = key < 0 ? 0 : 63 - (key & 63);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // LFC input: binarizeAndPack (foldedmv-offload.cpp:82-98) on the GPU.
 // 784 uint8 -> 13 words, bit i = (p >= 128), bits 784..831 zero.  One lane per
@@ -976,6 +1016,7 @@ inline bool narrow_for(long long items, int groups32, long long limit) { return 
 // 32-neuron grid (1024 images +10 %, 4096 +9 %); the FC stacks of the LFC nets (16-word inputs, 1024
 // neurons) lose beyond 512
 constexpr long long kNarrowLimitCnv = 8192, kNarrowLimitLfc = 512;
+constexpr long long kFcLastWaveMax = 32768;  // images: CNV layer 8 with a wave per image instead of a lane per image
 
 inline dim3 grid_for(long long items, int groups) {  // matches map_block()
   const long long item_blocks = (items + kBlock - 1) / kBlock;
@@ -1045,7 +1086,10 @@ void run_cnv_t(const CnvLaunch &a) {
     if (a.last_stage >= 7) BNN_STAGE((k_vec<ARITH, 8, OUT2, false, 1, 1>), (k_vec<ARITH, 8, OUT2, false, 1, 1, 8>), n, 16, A64, B, a.rows[7]);
     BNN_MARK(a.events, 8, s);
   }
-  if (a.last_stage >= 8) BNN_LAUNCH((k_fclast<ARITH, 8>), grid_for(n, 1), s, B64, a.scores, a.classes, a.rows[8], (int)n, a.number_class);
+  if (a.last_stage >= 8) {
+    if (n <= kFcLastWaveMax) BNN_LAUNCH((k_fclast_wave<ARITH, 8>), dim3((unsigned)((n + 3) / 4)), s, B64, a.scores, a.classes, a.rows[8], (int)n, a.number_class);
+    else BNN_LAUNCH((k_fclast<ARITH, 8>), grid_for(n, 1), s, B64, a.scores, a.classes, a.rows[8], (int)n, a.number_class);
+  }
   BNN_MARK(a.events, 9, s);
 }
 
