@@ -796,6 +796,91 @@ __global__ __launch_bounds__(kBlock) void k_fclast_wave(const uint64_t *__restri
   }
 }
 
+// cnvW1A1, small batches: layers 4..8 in ONE launch, a 512-thread block per image, thread = neuron
+// (the form of k_lfc_fused).  From the 5x5x128 map on, one image is too little work for a launch per
+// layer: five launches cost ~18 us of a 40 us single-image run, this kernel ~4 us.  Activations live
+// in LDS (400 B in, 288 / 32 / 64 / 64 B between the layers), a wave's ballot is the next layer's
+// input word, weight rows come from L2 per thread.
+template <int KW>
+__device__ __forceinline__ int xnor_row(const uint32_t *__restrict__ rows, int n, const uint64_t *act, int &thr) {
+  constexpr int ROW_DW = 2 + 2 * KW;
+  const uint32_t *__restrict__ r = rows + (size_t)n * ROW_DW;
+  const uint64_t *__restrict__ w = reinterpret_cast<const uint64_t *>(r + 2);
+  thr = (int)r[0];
+  int m = 0;
+#pragma unroll
+  for (int k = 0; k < KW; k++) m += pc64(w[k] ^ act[k]);
+  return m;
+}
+
+// (Requesting all five layers' rows up front, as k_lfc_fused does for the next layer, was measured: no
+// gain for one image, slower from 512 images on -- 169 VGPRs instead of 60.)
+__global__ __launch_bounds__(512) void k_cnv_tail(const uint64_t *__restrict__ in, int16_t *__restrict__ scores,
+                                                   int32_t *__restrict__ classes, const uint32_t *__restrict__ r4,
+                                                   const uint32_t *__restrict__ r5, const uint32_t *__restrict__ r6,
+                                                   const uint32_t *__restrict__ r7, const uint32_t *__restrict__ r8, int number_class) {
+  __shared__ uint64_t x3[50], x4[36], x5[4], x6[8], x7[8];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, img = blockIdx.x;
+  if (t < 50) x3[t] = in[(size_t)img * 50 + t];
+  __syncthreads();
+  {  // layer 4: 3x3 conv 5x5x128 -> 3x3x256; neuron = t & 255, the two halves of the block share the 9 pixels
+    constexpr int ROW_DW = 2 + 2 * 18;
+    const int n = t & 255;
+    const uint32_t *__restrict__ r = r4 + (size_t)n * ROW_DW;
+    const uint64_t *__restrict__ wp = reinterpret_cast<const uint64_t *>(r + 2);
+    const int thr = (int)r[0];
+    uint64_t w[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) w[k] = wp[k];
+    for (int p = (t >> 8); p < 9; p += 2) {  // wave-uniform: waves 0..3 take the even pixels, 4..7 the odd ones
+      const int oy = p / 3, ox = p - oy * 3;
+      int m = 0;
+#pragma unroll
+      for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+          for (int k = 0; k < 2; k++) m += pc64(w[(ky * 3 + kx) * 2 + k] ^ x3[((oy + ky) * 5 + ox + kx) * 2 + k]);
+      const uint64_t word = __ballot(m < thr);
+      if (lane == 0) x4[p * 4 + (wave & 3)] = word;
+    }
+  }
+  __syncthreads();
+  if (t < 256) {  // layer 5: the 3x3x256 map is one window: 36 words -> 256 neurons
+    int thr;
+    const int m = xnor_row<36>(r5, t, x4, thr);
+    const uint64_t word = __ballot(m < thr);
+    if (lane == 0) x5[wave] = word;
+  }
+  __syncthreads();
+  {  // layer 6: 256 -> 512
+    int thr;
+    const int m = xnor_row<4>(r6, t, x5, thr);
+    const uint64_t word = __ballot(m < thr);
+    if (lane == 0) x6[wave] = word;
+  }
+  __syncthreads();
+  {  // layer 7: 512 -> 512
+    int thr;
+    const int m = xnor_row<8>(r7, t, x6, thr);
+    const uint64_t word = __ballot(m < thr);
+    if (lane == 0) x7[wave] = word;
+  }
+  __syncthreads();
+  if (wave == 0) {  // layer 8: 512 -> 64 raw scores (popcount of matches) + the batched decode, as k_fclast_wave
+    int thr;
+    const int m = xnor_row<8>(r8, lane, x7, thr);
+    const int sc = (int)(int16_t)(8 * 64 - m);
+    if (scores) scores[(size_t)img * 64 + lane] = (int16_t)sc;
+    if (classes) {
+      int key = (lane < number_class && sc > 0) ? sc * 64 + (63 - lane) : -1;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) key = max(key, __shfl_xor(key, off, 64));
+      if (lane == 0) classes[img] = key < 0 ? 0 : 63 - (key & 63);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // LFC input: binarizeAndPack (foldedmv-offload.cpp:82-98) on the GPU.
 // 784 uint8 -> 13 words, bit i = (p >= 128), bits 784..831 zero.  One lane per
@@ -1016,7 +1101,8 @@ inline bool narrow_for(long long items, int groups32, long long limit) { return 
 // 32-neuron grid (1024 images +10 %, 4096 +9 %); the FC stacks of the LFC nets (16-word inputs, 1024
 // neurons) lose beyond 512
 constexpr long long kNarrowLimitCnv = 8192, kNarrowLimitLfc = 512;
-constexpr long long kFcLastWaveMax = 32768;  // images: CNV layer 8 with a wave per image instead of a lane per image
+constexpr long long kFcLastWaveMax = 32768;
+constexpr long long kCnvTailMax = 1024;  // images: cnvW1A1 layers 4..8 as one block-per-image launch (k_cnv_tail)  // images: CNV layer 8 with a wave per image instead of a lane per image
 
 inline dim3 grid_for(long long items, int groups) {  // matches map_block()
   const long long item_blocks = (items + kBlock - 1) / kBlock;
@@ -1062,6 +1148,12 @@ void run_cnv_t(const CnvLaunch &a) {
     BNN_MARK(a.events, 3, s);
     if (a.last_stage >= 3) BNN_STAGE((k_quad_x<2, 12, true>), (k_quad_x<2, 12, true, 8>), n * 25, 4, A64, B, a.rows[3]);
     BNN_MARK(a.events, 4, s);
+    if (n <= kCnvTailMax && !a.events && a.last_stage >= kCnvStages - 1) {
+      // small batch: layers 4..8 as one launch (no per-stage events there: there are no stages)
+      hipLaunchKernelGGL(k_cnv_tail, dim3((unsigned)n), dim3(512), 0, s, B64, a.scores, a.classes, a.rows[4], a.rows[5], a.rows[6],
+                         a.rows[7], a.rows[8], a.number_class);
+      return;
+    }
     if (a.last_stage >= 4) BNN_STAGE((k_vec_x<18, true, 2, 5>), (k_vec_x<18, true, 2, 5, 8>), n * 9, 8, B64, A, a.rows[4]);
     BNN_MARK(a.events, 5, s);
     if (a.last_stage >= 5) BNN_STAGE((k_vec_x<36, false, 1, 1>), (k_vec_x<36, false, 1, 1, 8>), n, 8, A64, B, a.rows[5]);

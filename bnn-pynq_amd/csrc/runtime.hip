@@ -378,6 +378,15 @@ struct ChunkReader {
     size_t nt = bytes / (4u << 20) + 1;
     if (nt > 8) nt = 8;
     if (hw && nt > hw) nt = hw;
+    if (nt == 1) {  // small read: not worth a thread
+      size_t done = 0;
+      while (done < bytes) {
+        const ssize_t got = ::pread(fd, dst + done, bytes - done, (off_t)(offset + done));
+        if (got <= 0) { ok = false; return; }
+        done += (size_t)got;
+      }
+      return;
+    }
     const size_t part = ((bytes + nt - 1) / nt + 4095) & ~(size_t)4095;
     for (size_t t = 0; t < nt; t++) {
       const size_t lo = t * part, hi = (lo + part < bytes) ? lo + part : bytes;
@@ -448,20 +457,24 @@ int stream_file(const ImageFile &f, int n, bool reuse_slots, Dst dst, Consume co
       span(c + 1, &off2, &m2);
       reader.start(f.fd, off2, (size_t)m2 * f.rec, r.h_file[slot ^ 1].get());
     }
-    if (c >= 2) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));  // d_file[slot] / dst free again
+    // one chunk: nothing to overlap, stay on the compute stream (fewer driver round trips for small calls)
+    hipStream_t cs = (nchunks == 1 && reuse_slots) ? r.stream : r.copy_stream;
+    if (c >= 2) HIP_OK(hipStreamWaitEvent(cs, r.consumed[slot], 0));  // d_file[slot] / dst free again
     uint8_t *packed = dst(c, slot);
     uint8_t *to = f.skip ? r.d_file[slot] : packed;
-    HIP_OK(hipMemcpyAsync(to, r.h_file[slot].get(), (size_t)m * f.rec, hipMemcpyHostToDevice, r.copy_stream));
-    HIP_OK(hipEventRecord(r.file_sent[slot], r.copy_stream));
+    HIP_OK(hipMemcpyAsync(to, r.h_file[slot].get(), (size_t)m * f.rec, hipMemcpyHostToDevice, cs));
+    if (nchunks > 1) HIP_OK(hipEventRecord(r.file_sent[slot], cs));
     if (f.skip) {
-      const hipError_t e = launch_strip_records(r.d_file[slot], (int)f.rec, (int)f.skip, packed, m, r.copy_stream);
+      const hipError_t e = launch_strip_records(r.d_file[slot], (int)f.rec, (int)f.skip, packed, m, cs);
       if (e != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(e));
     }
-    HIP_OK(hipEventRecord(r.copied[slot], r.copy_stream));
-    HIP_OK(hipStreamWaitEvent(r.stream, r.copied[slot], 0));
+    if (cs != r.stream) {
+      HIP_OK(hipEventRecord(r.copied[slot], cs));
+      HIP_OK(hipStreamWaitEvent(r.stream, r.copied[slot], 0));
+    }
     if (consume(c, base, m, slot)) return -1;
     // (with reuse_slots the consumer's stages read `packed`; without, only the strip kernel reads d_file[slot])
-    HIP_OK(hipEventRecord(r.consumed[slot], reuse_slots ? r.stream : r.copy_stream));
+    if (nchunks > 1) HIP_OK(hipEventRecord(r.consumed[slot], reuse_slots ? r.stream : r.copy_stream));
   }
   return 0;
 }
