@@ -881,6 +881,107 @@ __global__ __launch_bounds__(512) void k_cnv_tail(const uint64_t *__restrict__ i
   }
 }
 
+// The same for the 2-bit nets (cnvW1A2: AR_TB, cnvW2A2: AR_TT): activations are (sign, non-zero) plane
+// pairs, a layer's output planes come from the two ballots of a wave (fire_i <=> q + t_i < 0 with
+// q = 2m - nz resp. 2m - z, see k_quad), layer 8 yields the signed sums.
+template <int ARITH, int KW>
+__device__ __forceinline__ int ternary_q(const uint32_t *__restrict__ rows, int n, const uint64_t *sa, const uint64_t *za, int &t0, int &t1) {
+  constexpr int WPL = wplanes<ARITH>(), ROW_DW = 2 + 2 * KW * WPL;
+  const uint32_t *__restrict__ r = rows + (size_t)n * ROW_DW;
+  const uint64_t *__restrict__ w = reinterpret_cast<const uint64_t *>(r + 2);
+  t0 = (int)r[0];
+  t1 = (int)r[1];
+  int m = 0, z = 0;
+#pragma unroll
+  for (int k = 0; k < KW; k++) {
+    if constexpr (ARITH == AR_TB) {
+      m += pc64(za[k] & (sa[k] ^ w[k]));
+      z += pc64(za[k]);
+    } else {
+      const uint64_t zz = za[k] & w[2 * k + 1];
+      z += pc64(zz);
+      m += pc64(zz & (sa[k] ^ w[2 * k]));
+    }
+  }
+  return 2 * m - z;
+}
+
+template <int ARITH>
+__global__ __launch_bounds__(512) void k_cnv_tail_a2(const uint64_t *__restrict__ in, int16_t *__restrict__ scores,
+                                                      int32_t *__restrict__ classes, const uint32_t *__restrict__ r4,
+                                                      const uint32_t *__restrict__ r5, const uint32_t *__restrict__ r6,
+                                                      const uint32_t *__restrict__ r7, const uint32_t *__restrict__ r8, int number_class) {
+  // [plane 0 = sign, 1 = non-zero][word]
+  __shared__ uint64_t x3[2][50], x4[2][36], x5[2][4], x6[2][8], x7[2][8];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, img = blockIdx.x;
+  if (t < 100) x3[t & 1][t >> 1] = in[(size_t)img * 100 + t];  // stored [pixel][word][plane]
+  __syncthreads();
+  {  // layer 4
+    constexpr int WPL = wplanes<ARITH>(), ROW_DW = 2 + 2 * 18 * WPL;
+    const int n = t & 255;
+    const uint32_t *__restrict__ r = r4 + (size_t)n * ROW_DW;
+    const uint64_t *__restrict__ w = reinterpret_cast<const uint64_t *>(r + 2);
+    const int t0 = (int)r[0], t1 = (int)r[1];
+    for (int p = (t >> 8); p < 9; p += 2) {
+      const int oy = p / 3, ox = p - oy * 3;
+      int m = 0, z = 0;
+#pragma unroll
+      for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++)
+#pragma unroll
+          for (int k = 0; k < 2; k++) {
+            const int j = (ky * 3 + kx) * 2 + k, a = ((oy + ky) * 5 + ox + kx) * 2 + k;
+            const uint64_t sa = x3[0][a], za = x3[1][a];
+            if constexpr (ARITH == AR_TB) {
+              m += pc64(za & (sa ^ w[j]));
+              z += pc64(za);
+            } else {
+              const uint64_t zz = za & w[2 * j + 1];
+              z += pc64(zz);
+              m += pc64(zz & (sa ^ w[2 * j]));
+            }
+          }
+      const int q = 2 * m - z;
+      const uint64_t f0 = __ballot(q + t0 < 0), f1 = __ballot(q + t1 < 0);
+      if (lane == 0) { x4[0][p * 4 + (wave & 3)] = ~(f0 | f1); x4[1][p * 4 + (wave & 3)] = ~(f0 ^ f1); }
+    }
+  }
+  __syncthreads();
+  if (t < 256) {  // layer 5
+    int t0, t1;
+    const int q = ternary_q<ARITH, 36>(r5, t, x4[0], x4[1], t0, t1);
+    const uint64_t f0 = __ballot(q + t0 < 0), f1 = __ballot(q + t1 < 0);
+    if (lane == 0) { x5[0][wave] = ~(f0 | f1); x5[1][wave] = ~(f0 ^ f1); }
+  }
+  __syncthreads();
+  {  // layer 6
+    int t0, t1;
+    const int q = ternary_q<ARITH, 4>(r6, t, x5[0], x5[1], t0, t1);
+    const uint64_t f0 = __ballot(q + t0 < 0), f1 = __ballot(q + t1 < 0);
+    if (lane == 0) { x6[0][wave] = ~(f0 | f1); x6[1][wave] = ~(f0 ^ f1); }
+  }
+  __syncthreads();
+  {  // layer 7
+    int t0, t1;
+    const int q = ternary_q<ARITH, 8>(r7, t, x6[0], x6[1], t0, t1);
+    const uint64_t f0 = __ballot(q + t0 < 0), f1 = __ballot(q + t1 < 0);
+    if (lane == 0) { x7[0][wave] = ~(f0 | f1); x7[1][wave] = ~(f0 ^ f1); }
+  }
+  __syncthreads();
+  if (wave == 0) {  // layer 8: signed sums  nz - 2m  resp.  z - 2m  = -q
+    int t0, t1;
+    const int sc = (int)(int16_t)(-ternary_q<ARITH, 8>(r8, lane, x7[0], x7[1], t0, t1));
+    if (scores) scores[(size_t)img * 64 + lane] = (int16_t)sc;
+    if (classes) {
+      int key = (lane < number_class && sc > 0) ? sc * 64 + (63 - lane) : -1;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) key = max(key, __shfl_xor(key, off, 64));
+      if (lane == 0) classes[img] = key < 0 ? 0 : 63 - (key & 63);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // LFC input: binarizeAndPack (foldedmv-offload.cpp:82-98) on the GPU.
 // 784 uint8 -> 13 words, bit i = (p >= 128), bits 784..831 zero.  One lane per
@@ -1169,6 +1270,11 @@ void run_cnv_t(const CnvLaunch &a) {
     BNN_MARK(a.events, 3, s);
     if (a.last_stage >= 3) BNN_STAGE((k_quad<ARITH, 2, 12, true, OUT2>), (k_quad<ARITH, 2, 12, true, OUT2, 8>), n * 25, 4, A64, B, a.rows[3]);
     BNN_MARK(a.events, 4, s);
+    if (n <= kCnvTailMax && !a.events && a.last_stage >= kCnvStages - 1) {
+      hipLaunchKernelGGL(k_cnv_tail_a2<ARITH>, dim3((unsigned)n), dim3(512), 0, s, B64, a.scores, a.classes, a.rows[4], a.rows[5],
+                         a.rows[6], a.rows[7], a.rows[8], a.number_class);
+      return;
+    }
     if (a.last_stage >= 4) BNN_STAGE((k_vec<ARITH, 18, OUT2, true, 2, 5>), (k_vec<ARITH, 18, OUT2, true, 2, 5, 8>), n * 9, 8, B64, A, a.rows[4]);
     BNN_MARK(a.events, 5, s);
     if (a.last_stage >= 5) BNN_STAGE((k_vec<ARITH, 36, OUT2, false, 1, 1>), (k_vec<ARITH, 36, OUT2, false, 1, 1, 8>), n, 8, A64, B, a.rows[5]);
