@@ -439,19 +439,35 @@ __global__ __launch_bounds__(kBlock) void k_quad_x(const uint64_t *__restrict__ 
 
 // one lane = one vector of KW words (FC layers, CNV layer 5; SINGLE: CNV layer 4 window gather).
 // Two neurons per iteration: two independent v_bcnt chains per lane.
-template <int KW, bool SINGLE, int CW, int ID, int NPB = 32>
+// POOL (with SINGLE): lane = one output pixel of a 2x2-pooled conv layer, the four pixels of a pooling
+// quad on four consecutive lanes (item = 4 * quad + 2 dy + dx); the pooled bits are the OR over those
+// lanes.  Small batches only: four times the lanes of k_quad_x, a quarter of the work per lane.
+template <int KW, bool SINGLE, int CW, int ID, int NPB = 32, bool POOL = false>
 __global__ __launch_bounds__(kBlock) void k_vec_x(const uint64_t *__restrict__ in, uint32_t *__restrict__ out,
                                                    const uint32_t *__restrict__ rows, int n_items, int groups, int gpb) {
   constexpr int ROW_DW = 2 + 2 * KW;
+  static_assert(!POOL || SINGLE, "pooling needs the window form");
   const BlockMap bm = map_block(groups / gpb, n_items);
-  if (!bm.valid) return;
+  if (!bm.valid) return;  // (POOL: n_items is a multiple of 4, so a quad is valid or invalid as a whole)
   const int item = bm.item;
   uint32_t al[KW], ah[KW];
   if constexpr (SINGLE) {
     constexpr int OD = ID - 2;
     static_assert(KW == 9 * CW, "window size");
-    const int img = item / (OD * OD), p = item - img * (OD * OD);
-    const int oy = p / OD, ox = p - oy * OD;
+    int img, oy, ox;
+    if constexpr (POOL) {
+      constexpr int QD = OD / 2, NQ = QD * QD;
+      const int quad = item >> 2, sub = item & 3;
+      img = quad / NQ;
+      const int q = quad - img * NQ, qy = q / QD, qx = q - qy * QD;
+      oy = 2 * qy + (sub >> 1);
+      ox = 2 * qx + (sub & 1);
+    } else {
+      img = item / (OD * OD);
+      const int p = item - img * (OD * OD);
+      oy = p / OD;
+      ox = p - oy * OD;
+    }
     const uint64_t *__restrict__ base = in + ((size_t)img * ID * ID + (size_t)oy * ID + ox) * CW;
 #pragma unroll
     for (int ky = 0; ky < 3; ky++)
@@ -490,7 +506,13 @@ __global__ __launch_bounds__(kBlock) void k_vec_x(const uint64_t *__restrict__ i
       b = shift_in_sign(b, m1 - (int)r1[0]);
       b = shift_in_sign(b, m0 - (int)r0[0]);
     }
-    store_group<NPB>(out, (size_t)item * groups + cg, b);
+    if constexpr (POOL) {
+      b |= __shfl_xor(b, 1, 64);
+      b |= __shfl_xor(b, 2, 64);
+      if ((item & 3) == 0) store_group<NPB>(out, (size_t)(item >> 2) * groups + cg, b);
+    } else {
+      store_group<NPB>(out, (size_t)item * groups + cg, b);
+    }
   }
 }
 
@@ -1203,6 +1225,7 @@ inline bool narrow_for(long long items, int groups32, long long limit) { return 
 // neurons) lose beyond 512
 constexpr long long kNarrowLimitCnv = 8192, kNarrowLimitLfc = 512;
 constexpr long long kFcLastWaveMax = 32768;
+constexpr long long kPixelLaneMax = 512;    // images: cnvW1A1 layers 1..3 with a lane per output pixel
 constexpr long long kCnvTailMax = 1024;  // images: cnvW1A1 layers 4..8 as one block-per-image launch (k_cnv_tail)  // images: CNV layer 8 with a wave per image instead of a lane per image
 
 inline dim3 grid_for(long long items, int groups) {  // matches map_block()
@@ -1243,11 +1266,23 @@ void run_cnv_t(const CnvLaunch &a) {
   }
   BNN_MARK(a.events, 1, s);
   if constexpr (ARITH == AR_XNOR && !OUT2) {
-    if (a.last_stage >= 1) BNN_STAGE((k_quad_x<1, 30, true>), (k_quad_x<1, 30, true, 8>), n * 196, 2, A64, B, a.rows[1]);
+    // tiny batches: a lane per output PIXEL instead of per 2x2 quad (k_vec_x in its window form, 8 neurons
+    // per block): four times the lanes, a quarter of the serial work of each
+    const bool pix = n <= kPixelLaneMax;
+    if (a.last_stage >= 1) {
+      if (pix) BNN_LAUNCH((k_vec_x<9, true, 1, 30, 8, true>), grid_for(n * 784, 8), s, A64, B, a.rows[1], (int)(n * 784), 8, 1);
+      else BNN_STAGE((k_quad_x<1, 30, true>), (k_quad_x<1, 30, true, 8>), n * 196, 2, A64, B, a.rows[1]);
+    }
     BNN_MARK(a.events, 2, s);
-    if (a.last_stage >= 2) BNN_STAGE((k_quad_x<1, 14, false>), (k_quad_x<1, 14, false, 8>), n * 36, 4, B64, A, a.rows[2]);
+    if (a.last_stage >= 2) {
+      if (pix) BNN_LAUNCH((k_vec_x<9, true, 1, 14, 8>), grid_for(n * 144, 16), s, B64, A, a.rows[2], (int)(n * 144), 16, 1);
+      else BNN_STAGE((k_quad_x<1, 14, false>), (k_quad_x<1, 14, false, 8>), n * 36, 4, B64, A, a.rows[2]);
+    }
     BNN_MARK(a.events, 3, s);
-    if (a.last_stage >= 3) BNN_STAGE((k_quad_x<2, 12, true>), (k_quad_x<2, 12, true, 8>), n * 25, 4, A64, B, a.rows[3]);
+    if (a.last_stage >= 3) {
+      if (pix) BNN_LAUNCH((k_vec_x<18, true, 2, 12, 8, true>), grid_for(n * 100, 16), s, A64, B, a.rows[3], (int)(n * 100), 16, 1);
+      else BNN_STAGE((k_quad_x<2, 12, true>), (k_quad_x<2, 12, true, 8>), n * 25, 4, A64, B, a.rows[3]);
+    }
     BNN_MARK(a.events, 4, s);
     if (n <= kCnvTailMax && !a.events && a.last_stage >= kCnvStages - 1) {
       // small batch: layers 4..8 as one launch (no per-stage events there: there are no stages)
