@@ -665,11 +665,13 @@ __global__ __launch_bounds__(kBlock) void k_quad(const uint64_t *__restrict__ in
 
 // Generic "KW words in, thresholded bits out": one lane = one vector (FC layers, CNV layer 5,
 // and with SINGLE the 3x3 window gather of CNV layer 4).  Two neurons per iteration.
-template <int ARITH, int KW, bool OUT2, bool SINGLE, int CW, int ID, int NPB = 32>
+// POOL: as in k_vec_x (lane = output pixel, quad on four consecutive lanes, OR of the fire words).
+template <int ARITH, int KW, bool OUT2, bool SINGLE, int CW, int ID, int NPB = 32, bool POOL = false>
 __global__ __launch_bounds__(kBlock) void k_vec(const uint64_t *__restrict__ in, uint32_t *__restrict__ out,
                                                  const uint32_t *__restrict__ rows, int n_items, int groups, int gpb) {
   constexpr int PL = planes_in<ARITH>(), WPL = wplanes<ARITH>();
   constexpr int ROW_DW = 2 + 2 * KW * WPL, ZW = (PL == 2) ? KW : 1;
+  static_assert(!POOL || SINGLE, "pooling needs the window form");
   const BlockMap bm = map_block(groups / gpb, n_items);
   if (!bm.valid) return;
   const int item = bm.item;
@@ -685,8 +687,20 @@ __global__ __launch_bounds__(kBlock) void k_vec(const uint64_t *__restrict__ in,
   if constexpr (SINGLE) {
     constexpr int OD = ID - 2;
     static_assert(KW == 9 * CW, "window size");
-    const int img = item / (OD * OD), p = item - img * (OD * OD);
-    const int oy = p / OD, ox = p - oy * OD;
+    int img, oy, ox;
+    if constexpr (POOL) {
+      constexpr int QD = OD / 2, NQ = QD * QD;
+      const int quad = item >> 2, sub = item & 3;
+      img = quad / NQ;
+      const int q = quad - img * NQ, qy = q / QD, qx = q - qy * QD;
+      oy = 2 * qy + (sub >> 1);
+      ox = 2 * qx + (sub & 1);
+    } else {
+      img = item / (OD * OD);
+      const int p = item - img * (OD * OD);
+      oy = p / OD;
+      ox = p - oy * OD;
+    }
     const uint64_t *__restrict__ base = in + ((size_t)img * ID * ID + (size_t)oy * ID + ox) * CW * PL;
 #pragma unroll
     for (int ky = 0; ky < 3; ky++)
@@ -726,8 +740,16 @@ __global__ __launch_bounds__(kBlock) void k_vec(const uint64_t *__restrict__ in,
         decide<OUT2>(b0, b1, q_of<ARITH>(mB, zB, nn) + tB0, tB1 - tB0);
       }
     }
+    if constexpr (POOL) {  // max-pool of a thresholded map = OR of each threshold's fire bits over the quad
+      b0 |= __shfl_xor(b0, 1, 64);
+      b0 |= __shfl_xor(b0, 2, 64);
+      if constexpr (OUT2) {
+        b1 |= __shfl_xor(b1, 1, 64);
+        b1 |= __shfl_xor(b1, 2, 64);
+      }
+    }
     finish_bits<OUT2>(b0, b1);
-    store_bits<OUT2, NPB>(out, (size_t)item, groups, cg, b0, b1);
+    if (!POOL || (item & 3) == 0) store_bits<OUT2, NPB>(out, (size_t)(POOL ? item >> 2 : item), groups, cg, b0, b1);
   }
 }
 
@@ -1299,11 +1321,21 @@ void run_cnv_t(const CnvLaunch &a) {
     if (a.last_stage >= 7) BNN_STAGE((k_vec_x<8, false, 1, 1>), (k_vec_x<8, false, 1, 1, 8>), n, 16, A64, B, a.rows[7]);
     BNN_MARK(a.events, 8, s);
   } else {
-    if (a.last_stage >= 1) BNN_STAGE((k_quad<ARITH, 1, 30, true, OUT2>), (k_quad<ARITH, 1, 30, true, OUT2, 8>), n * 196, 2, A64, B, a.rows[1]);
+    const bool pix = n <= kPixelLaneMax;  // tiny batches: a lane per output pixel (see the XNOR branch)
+    if (a.last_stage >= 1) {
+      if (pix) BNN_LAUNCH((k_vec<ARITH, 9, OUT2, true, 1, 30, 8, true>), grid_for(n * 784, 8), s, A64, B, a.rows[1], (int)(n * 784), 8, 1);
+      else BNN_STAGE((k_quad<ARITH, 1, 30, true, OUT2>), (k_quad<ARITH, 1, 30, true, OUT2, 8>), n * 196, 2, A64, B, a.rows[1]);
+    }
     BNN_MARK(a.events, 2, s);
-    if (a.last_stage >= 2) BNN_STAGE((k_quad<ARITH, 1, 14, false, OUT2>), (k_quad<ARITH, 1, 14, false, OUT2, 8>), n * 36, 4, B64, A, a.rows[2]);
+    if (a.last_stage >= 2) {
+      if (pix) BNN_LAUNCH((k_vec<ARITH, 9, OUT2, true, 1, 14, 8>), grid_for(n * 144, 16), s, B64, A, a.rows[2], (int)(n * 144), 16, 1);
+      else BNN_STAGE((k_quad<ARITH, 1, 14, false, OUT2>), (k_quad<ARITH, 1, 14, false, OUT2, 8>), n * 36, 4, B64, A, a.rows[2]);
+    }
     BNN_MARK(a.events, 3, s);
-    if (a.last_stage >= 3) BNN_STAGE((k_quad<ARITH, 2, 12, true, OUT2>), (k_quad<ARITH, 2, 12, true, OUT2, 8>), n * 25, 4, A64, B, a.rows[3]);
+    if (a.last_stage >= 3) {
+      if (pix) BNN_LAUNCH((k_vec<ARITH, 18, OUT2, true, 2, 12, 8, true>), grid_for(n * 100, 16), s, A64, B, a.rows[3], (int)(n * 100), 16, 1);
+      else BNN_STAGE((k_quad<ARITH, 2, 12, true, OUT2>), (k_quad<ARITH, 2, 12, true, OUT2, 8>), n * 25, 4, A64, B, a.rows[3]);
+    }
     BNN_MARK(a.events, 4, s);
     if (n <= kCnvTailMax && !a.events && a.last_stage >= kCnvStages - 1) {
       hipLaunchKernelGGL(k_cnv_tail_a2<ARITH>, dim3((unsigned)n), dim3(512), 0, s, B64, a.scores, a.classes, a.rows[4], a.rows[5],
