@@ -161,3 +161,38 @@ def test_campaign_on_gpu_replayed_in_oracle(network, dataset, target, word_size,
     fresh = np.ctypeslib.as_array(p, shape=(n,)).copy()
     L.free_results(p)
     assert fresh.tolist() == clean.tolist()
+
+
+@pytest.mark.gpu
+def test_campaign_over_a_multi_chunk_file(tmp_path):
+    """70 000 MNIST images: the resident load streams three 32 768-image chunks, runs of images between
+    fault times cross chunk borders; replayed in the oracle like the small campaigns"""
+    network, dataset, n, flips = "lfcW1A1", "mnist", 70000, 40
+    L = gl.load(network)
+    pdir = gl.param_dir(dataset, network)
+    L.load_parameters(pdir.encode())
+    imgs = np.random.default_rng(23).integers(0, 256, (n, 784), dtype=np.uint8)
+    path = tmp_path / "imgs-idx3-ubyte"
+    with open(path, "wb") as f:
+        f.write(struct.pack(">4I", 0x803, n, 28, 28) + imgs.tobytes())
+    assert L.bnn_mi355x_set_fault_seed(99) == 0
+    cnt = C.c_int(0)
+    p = L.inference_multiple_with_faults(str(path).encode(), 10, C.byref(cnt), None, flips, 8, 0, None, 0)
+    assert p and cnt.value == n
+    got = np.ctypeslib.as_array(p, shape=(n,)).copy()
+    L.free_results(p)
+    rec = (C.c_int * (8 * flips))()
+    assert L.bnn_mi355x_last_faults(rec, flips) == flips
+    recs = np.array(rec[:], np.int32).reshape(flips, 8)
+    o = ol.Oracle(network, pdir)
+    want = np.zeros(n, np.int32)
+    k, start = 0, 0
+    while start < n:
+        while k < flips and recs[k, 0] <= start:
+            assert o.apply_fault(recs[k]) >= 0
+            k += 1
+        end = int(recs[k, 0]) if k < flips else n
+        want[start:end] = o.classes_batched(imgs[start:end], 10)
+        start = end
+    assert got.tolist() == want.tolist()
+    L.load_parameters(pdir.encode())
