@@ -7,8 +7,8 @@ while the input set is classified, and reports the accuracy of each run.  ``Netw
 fault counts x {any, weight, threshold} x {bit, word}, writes the raw accuracies and the statistics
 (min / max / average, "effective" runs = runs whose accuracy differs from the control) as JSON.
 
-On the MI355X runtime a run of 10 000 CIFAR-10 images with 100 upsets takes about 8 ms plus the
-parameter reload (tools/fault_campaign_rate.py).
+On the MI355X runtime a run of 10 000 CIFAR-10 images with 100 upsets takes about 5 ms plus the
+3 ms parameter reload (tools/fault_campaign_rate.py).
 """
 from .. import bnn as _bnn
 from .. import util
