@@ -45,7 +45,8 @@ def layout(network):
 
 
 def write_params(directory, network, weights, thresholds, classes=None):
-    """weights[l]: int array [MH, MW] with values in {-1,+1} (1-bit) or {-1,0,+1} (2-bit);
+    """weights[l]: int array [MH, MW] with values in {-1,+1} (1-bit) or {-1,0,+1} (2-bit; -2, the fourth
+    ap_int<2> value, is written too: trained sets never hold it, fault-injected ones do);
     thresholds[l]: int array [MH, nThr] (ignored where nThr == 0), raw integers as stored
     (layer 0 of the CNV nets: units of 2^-8).  Writes the reference's file set."""
     os.makedirs(directory, exist_ok=True)
@@ -55,7 +56,7 @@ def write_params(directory, network, weights, thresholds, classes=None):
         if L["wbits"] == 1:
             fields = (W > 0).astype(np.uint64)
         else:
-            fields = np.where(W < 0, 3, W).astype(np.uint64)  # ap_int<2>: -1 -> 0b11
+            fields = (W.astype(np.int64) & 3).astype(np.uint64)  # ap_int<2> two's complement: -1 -> 0b11, -2 -> 0b10
         f = fields.reshape(L["mh"], sf, L["simd"])
         shifts = (np.arange(L["simd"], dtype=np.uint64) * np.uint64(L["wbits"]))
         words = np.bitwise_or.reduce(f << shifts, axis=2)  # [MH, SF]

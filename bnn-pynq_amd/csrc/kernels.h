@@ -13,6 +13,7 @@ struct CnvLaunch {
   void *buf0, *buf1;          // device ping-pong activation buffers (cnv_workspace_bytes per image)
   const uint32_t *rows[9];    // device, per-layer packed rows (packed_params.h)
   const uint8_t *l0_mfma;     // device, layer-0 MFMA table (packed_params.h); null: integer-pipe k_conv0
+  bool has_two;               // cnvW2A2: some row holds a weight of -2 (fault injection): the -2-aware kernel variants
   int16_t *scores;            // device, n x 64, may be null
   int32_t *classes;           // device, n, may be null
   int number_class;

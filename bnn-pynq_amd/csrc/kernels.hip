@@ -31,6 +31,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace bnn {
@@ -115,6 +117,26 @@ template <int ARITH>
 constexpr int planes_in() { return ARITH == AR_XNOR ? 1 : 2; }
 template <int ARITH>
 constexpr int wplanes() { return ARITH == AR_TT ? 2 : 1; }
+// dwords per packed row (packed_params.cpp): {t0, t1, KW x weight planes}; AR_TT rows carry, behind the two
+// planes, a third one marking the columns whose weight is -2, then a flag dword ("any such column") and a pad
+// dword
+template <int ARITH, int KW>
+constexpr int row_dw() { return ARITH == AR_TT ? 4 + 6 * KW : 2 + 2 * KW * wplanes<ARITH>(); }
+// ap_int<2> weights can be -2 (field 0b10): never in trained parameters, but one bit flip away from 0 and
+// from -1, and the reference then multiplies by -2.  The kernels evaluate such a column as -1 (it is set in
+// the sign and non-zero planes) and, for rows whose flag is set, add the missing -a_j:
+// z += [a_j = -1] - [a_j = +1].  That code lives in separate instantiations (template parameter TWO) which
+// the host selects only while some row of the network has its flag set (runtime.hip): inside the normal
+// kernels it would cost registers -- occupancy is decided by the worst path of a kernel -- and scalar-load
+// waits that the fault-free path must not pay.
+__device__ __forceinline__ int two_extra(uint32_t two, uint32_t as, uint32_t az) {
+  const uint32_t x = two & az;
+  return 2 * __builtin_popcount(x & as) - __builtin_popcount(x);
+}
+__device__ __forceinline__ int two_extra64(uint64_t two, uint64_t as, uint64_t az) {
+  const uint64_t x = two & az;
+  return 2 * __builtin_popcountll(x & as) - __builtin_popcountll(x);
+}
 
 // (m, z, nz_total) -> the signed accumulator of the ternary forms (used by the last CNV layer)
 template <int ARITH>
@@ -579,11 +601,11 @@ __device__ __forceinline__ void finish_bits(uint32_t &b0, uint32_t &b1) {
 // 3x3 valid conv, one lane = a 2x2 quad of output pixels (4x4 window in VGPRs), optional pool.
 // Replaces ConvolutionInputGenerator + Matrix_Vector_Activate_Batch + ThresholdsActivation
 // (+ StreamingMaxPool_Precision_Batch) for CNV layers 1..3 of the A2 networks.
-template <int ARITH, int CW, int ID, bool POOL, bool OUT2, int NPB = 32>
+template <int ARITH, int CW, int ID, bool POOL, bool OUT2, int NPB = 32, bool TWO = false>
 __global__ __launch_bounds__(kBlock) void k_quad(const uint64_t *__restrict__ in, uint32_t *__restrict__ out,
                                                   const uint32_t *__restrict__ rows, int n_items, int groups, int gpb) {
   constexpr int OD = ID - 2, QD = OD / 2, NQ = QD * QD, PL = planes_in<ARITH>(), WPL = wplanes<ARITH>();
-  constexpr int KW = 9 * CW, ROW_DW = 2 + 2 * KW * WPL, ZW = (PL == 2) ? CW : 1;
+  constexpr int KW = 9 * CW, ROW_DW = row_dw<ARITH, KW>(), ZW = (PL == 2) ? CW : 1;
   const BlockMap bm = map_block(groups / gpb, n_items);
   if (!bm.valid) return;
   const int item = bm.item;
@@ -639,6 +661,22 @@ __global__ __launch_bounds__(kBlock) void k_quad(const uint64_t *__restrict__ in
             for (int dx = 0; dx < 2; dx++)
               mac32<ARITH>(m[dy][dx], z[dy][dx], ws[dy + ky][dx + kx][k][h], wz[dy + ky][dx + kx][PL == 2 ? k : 0][h], wq, h);
       }
+      if constexpr (TWO) {
+        if (r[2 + 6 * KW]) {  // this neuron has weights of -2 (fault injection only)
+  #pragma unroll
+          for (int j = 0; j < KW; j++) {
+            const int ky = j / (3 * CW), kx = (j / CW) % 3, k = j % CW;
+  #pragma unroll
+            for (int h = 0; h < 2; h++) {
+              const uint32_t two = r[2 + 4 * KW + 2 * j + h];
+  #pragma unroll
+              for (int dy = 0; dy < 2; dy++)
+  #pragma unroll
+                for (int dx = 0; dx < 2; dx++) z[dy][dx] += two_extra(two, ws[dy + ky][dx + kx][k][h], wz[dy + ky][dx + kx][k][h]);
+            }
+          }
+        }
+      }
       if constexpr (POOL) {
         const int q0 = q_of<ARITH>(m[0][0], z[0][0], nn[0][0]), q1 = q_of<ARITH>(m[0][1], z[0][1], nn[0][1]);
         const int q2 = q_of<ARITH>(m[1][0], z[1][0], nn[1][0]), q3 = q_of<ARITH>(m[1][1], z[1][1], nn[1][1]);
@@ -666,11 +704,11 @@ __global__ __launch_bounds__(kBlock) void k_quad(const uint64_t *__restrict__ in
 // Generic "KW words in, thresholded bits out": one lane = one vector (FC layers, CNV layer 5,
 // and with SINGLE the 3x3 window gather of CNV layer 4).  Two neurons per iteration.
 // POOL: as in k_vec_x (lane = output pixel, quad on four consecutive lanes, OR of the fire words).
-template <int ARITH, int KW, bool OUT2, bool SINGLE, int CW, int ID, int NPB = 32, bool POOL = false>
+template <int ARITH, int KW, bool OUT2, bool SINGLE, int CW, int ID, int NPB = 32, bool POOL = false, bool TWO = false>
 __global__ __launch_bounds__(kBlock) void k_vec(const uint64_t *__restrict__ in, uint32_t *__restrict__ out,
                                                  const uint32_t *__restrict__ rows, int n_items, int groups, int gpb) {
   constexpr int PL = planes_in<ARITH>(), WPL = wplanes<ARITH>();
-  constexpr int ROW_DW = 2 + 2 * KW * WPL, ZW = (PL == 2) ? KW : 1;
+  constexpr int ROW_DW = row_dw<ARITH, KW>(), ZW = (PL == 2) ? KW : 1;
   static_assert(!POOL || SINGLE, "pooling needs the window form");
   const BlockMap bm = map_block(groups / gpb, n_items);
   if (!bm.valid) return;
@@ -731,6 +769,17 @@ __global__ __launch_bounds__(kBlock) void k_vec(const uint64_t *__restrict__ in,
           mac32<ARITH>(mA, zA, as[k][h], az[PL == 2 ? k : 0][h], rA + 2 + 2 * WPL * k, h);
           mac32<ARITH>(mB, zB, as[k][h], az[PL == 2 ? k : 0][h], rB + 2 + 2 * WPL * k, h);
         }
+      if constexpr (TWO) {
+        if (rA[2 + 6 * KW] | rB[2 + 6 * KW]) {  // weights of -2 in one of the two rows (fault injection only)
+  #pragma unroll
+          for (int k = 0; k < KW; k++)
+  #pragma unroll
+            for (int h = 0; h < 2; h++) {
+              zA += two_extra(rA[2 + 4 * KW + 2 * k + h], as[k][h], az[k][h]);
+              zB += two_extra(rB[2 + 4 * KW + 2 * k + h], as[k][h], az[k][h]);
+            }
+        }
+      }
       const int tA0 = (int)rA[0], tA1 = (int)rA[1], tB0 = (int)rB[0], tB1 = (int)rB[1];
       if constexpr (ARITH == AR_XNOR) {
         decide<OUT2>(b0, b1, mA - tA0, tA0 - tA1);
@@ -760,12 +809,12 @@ __global__ __launch_bounds__(kBlock) void k_vec(const uint64_t *__restrict__ in,
 // strict maximum over the first number_class scores, floored at 0.
 // AR_XNOR score = popcount of matches = MW - m; ternary nets: the signed sum.
 // ---------------------------------------------------------------------------
-template <int ARITH, int KW>
+template <int ARITH, int KW, bool TWO = false>
 __global__ __launch_bounds__(kBlock) void k_fclast(const uint64_t *__restrict__ in, int16_t *__restrict__ scores,
                                                     int32_t *__restrict__ classes, const uint32_t *__restrict__ rows,
                                                     int n_items, int number_class) {
   constexpr int PL = planes_in<ARITH>(), WPL = wplanes<ARITH>();
-  constexpr int ROW_DW = 2 + 2 * KW * WPL;
+  constexpr int ROW_DW = row_dw<ARITH, KW>();
   const int item = blockIdx.x * kBlock + threadIdx.x;
   if (item >= n_items) return;
   uint64_t as[KW], az[PL == 2 ? KW : 1];
@@ -789,6 +838,12 @@ __global__ __launch_bounds__(kBlock) void k_fclast(const uint64_t *__restrict__ 
     int m = 0, z = 0;
 #pragma unroll
     for (int k = 0; k < KW; k++) mac<ARITH>(m, z, as[k], az[PL == 2 ? k : 0], rw + k * WPL);
+    if constexpr (TWO) {
+      if (w[n * ROW_DW + 2 + 6 * KW]) {  // weights of -2 in this row (fault injection only)
+#pragma unroll
+        for (int k = 0; k < KW; k++) z += two_extra64(rw[2 * KW + k], as[k], az[k]);
+      }
+    }
     int s = (ARITH == AR_XNOR) ? (KW * 64 - m) : finish<ARITH>(m, z, nzt);
     s = (int)(int16_t)s;  // 16-bit output word read back as ap_int<16>
     if (n < number_class && s > bestv) { bestv = s; best = n; }
@@ -804,12 +859,12 @@ __global__ __launch_bounds__(kBlock) void k_fclast(const uint64_t *__restrict__ 
 // lane per image a single image is a serial chain of 64 neurons x 8 words on one lane (13 us); here it is
 // 8 words per lane and a wave reduction for the decode.  key = score * 64 + (63 - neuron) orders by score,
 // then by lowest index; scores <= 0 never beat the initial (class 0, value 0) of the reference's loop.
-template <int ARITH, int KW>
+template <int ARITH, int KW, bool TWO = false>
 __global__ __launch_bounds__(kBlock) void k_fclast_wave(const uint64_t *__restrict__ in, int16_t *__restrict__ scores,
                                                          int32_t *__restrict__ classes, const uint32_t *__restrict__ rows,
                                                          int n_items, int number_class) {
-  constexpr int PL = planes_in<ARITH>(), WPL = wplanes<ARITH>();
-  constexpr int ROW_DW = 2 + 2 * KW * WPL;
+  constexpr int PL = planes_in<ARITH>();
+  constexpr int ROW_DW = row_dw<ARITH, KW>();
   const int lane = threadIdx.x & 63, item = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (item >= n_items) return;  // wave-uniform
   const uint64_t *__restrict__ base = in + (size_t)item * KW * PL;
@@ -827,6 +882,12 @@ __global__ __launch_bounds__(kBlock) void k_fclast_wave(const uint64_t *__restri
       const uint64_t zz = az & rw[k * 2 + 1];
       z += pc64(zz);
       m += pc64(zz & (as ^ rw[k * 2]));
+    }
+  }
+  if constexpr (TWO) {
+    if (rows[(size_t)lane * ROW_DW + 2 + 6 * KW]) {  // per lane here: each lane is its own neuron
+#pragma unroll
+      for (int k = 0; k < KW; k++) z += two_extra64(rw[2 * KW + k], base[k * PL], base[k * PL + 1]);
     }
   }
   int sc = (ARITH == AR_XNOR) ? (KW * 64 - m) : finish<ARITH>(m, z, nzt);
@@ -928,9 +989,9 @@ __global__ __launch_bounds__(512) void k_cnv_tail(const uint64_t *__restrict__ i
 // The same for the 2-bit nets (cnvW1A2: AR_TB, cnvW2A2: AR_TT): activations are (sign, non-zero) plane
 // pairs, a layer's output planes come from the two ballots of a wave (fire_i <=> q + t_i < 0 with
 // q = 2m - nz resp. 2m - z, see k_quad), layer 8 yields the signed sums.
-template <int ARITH, int KW>
+template <int ARITH, int KW, bool TWO>
 __device__ __forceinline__ int ternary_q(const uint32_t *__restrict__ rows, int n, const uint64_t *sa, const uint64_t *za, int &t0, int &t1) {
-  constexpr int WPL = wplanes<ARITH>(), ROW_DW = 2 + 2 * KW * WPL;
+  constexpr int ROW_DW = row_dw<ARITH, KW>();
   const uint32_t *__restrict__ r = rows + (size_t)n * ROW_DW;
   const uint64_t *__restrict__ w = reinterpret_cast<const uint64_t *>(r + 2);
   t0 = (int)r[0];
@@ -947,10 +1008,16 @@ __device__ __forceinline__ int ternary_q(const uint32_t *__restrict__ rows, int 
       m += pc64(zz & (sa[k] ^ w[2 * k]));
     }
   }
+  if constexpr (TWO) {
+    if (r[2 + 6 * KW]) {  // weights of -2 in this row (fault injection only); thread = neuron: a per-lane branch
+#pragma unroll
+      for (int k = 0; k < KW; k++) z += two_extra64(w[2 * KW + k], sa[k], za[k]);
+    }
+  }
   return 2 * m - z;
 }
 
-template <int ARITH>
+template <int ARITH, bool TWO = false>
 __global__ __launch_bounds__(512) void k_cnv_tail_a2(const uint64_t *__restrict__ in, int16_t *__restrict__ scores,
                                                       int32_t *__restrict__ classes, const uint32_t *__restrict__ r4,
                                                       const uint32_t *__restrict__ r5, const uint32_t *__restrict__ r6,
@@ -961,11 +1028,13 @@ __global__ __launch_bounds__(512) void k_cnv_tail_a2(const uint64_t *__restrict_
   if (t < 100) x3[t & 1][t >> 1] = in[(size_t)img * 100 + t];  // stored [pixel][word][plane]
   __syncthreads();
   {  // layer 4
-    constexpr int WPL = wplanes<ARITH>(), ROW_DW = 2 + 2 * 18 * WPL;
+    constexpr int ROW_DW = row_dw<ARITH, 18>();
     const int n = t & 255;
     const uint32_t *__restrict__ r = r4 + (size_t)n * ROW_DW;
     const uint64_t *__restrict__ w = reinterpret_cast<const uint64_t *>(r + 2);
     const int t0 = (int)r[0], t1 = (int)r[1];
+    bool has_two = false;  // weights of -2 in this row (fault injection only)
+    if constexpr (TWO) has_two = r[2 + 6 * 18] != 0;
     for (int p = (t >> 8); p < 9; p += 2) {
       const int oy = p / 3, ox = p - oy * 3;
       int m = 0, z = 0;
@@ -986,6 +1055,12 @@ __global__ __launch_bounds__(512) void k_cnv_tail_a2(const uint64_t *__restrict_
               m += pc64(zz & (sa ^ w[2 * j]));
             }
           }
+      if (has_two) {  // kept out of the loop above: the fault-free path must not carry these loads
+        for (int j = 0; j < 18; j++) {
+          const int tap = j >> 1, a = ((oy + tap / 3) * 5 + ox + tap % 3) * 2 + (j & 1);
+          z += two_extra64(w[2 * 18 + j], x3[0][a], x3[1][a]);
+        }
+      }
       const int q = 2 * m - z;
       const uint64_t f0 = __ballot(q + t0 < 0), f1 = __ballot(q + t1 < 0);
       if (lane == 0) { x4[0][p * 4 + (wave & 3)] = ~(f0 | f1); x4[1][p * 4 + (wave & 3)] = ~(f0 ^ f1); }
@@ -994,28 +1069,28 @@ __global__ __launch_bounds__(512) void k_cnv_tail_a2(const uint64_t *__restrict_
   __syncthreads();
   if (t < 256) {  // layer 5
     int t0, t1;
-    const int q = ternary_q<ARITH, 36>(r5, t, x4[0], x4[1], t0, t1);
+    const int q = ternary_q<ARITH, 36, TWO>(r5, t, x4[0], x4[1], t0, t1);
     const uint64_t f0 = __ballot(q + t0 < 0), f1 = __ballot(q + t1 < 0);
     if (lane == 0) { x5[0][wave] = ~(f0 | f1); x5[1][wave] = ~(f0 ^ f1); }
   }
   __syncthreads();
   {  // layer 6
     int t0, t1;
-    const int q = ternary_q<ARITH, 4>(r6, t, x5[0], x5[1], t0, t1);
+    const int q = ternary_q<ARITH, 4, TWO>(r6, t, x5[0], x5[1], t0, t1);
     const uint64_t f0 = __ballot(q + t0 < 0), f1 = __ballot(q + t1 < 0);
     if (lane == 0) { x6[0][wave] = ~(f0 | f1); x6[1][wave] = ~(f0 ^ f1); }
   }
   __syncthreads();
   {  // layer 7
     int t0, t1;
-    const int q = ternary_q<ARITH, 8>(r7, t, x6[0], x6[1], t0, t1);
+    const int q = ternary_q<ARITH, 8, TWO>(r7, t, x6[0], x6[1], t0, t1);
     const uint64_t f0 = __ballot(q + t0 < 0), f1 = __ballot(q + t1 < 0);
     if (lane == 0) { x7[0][wave] = ~(f0 | f1); x7[1][wave] = ~(f0 ^ f1); }
   }
   __syncthreads();
   if (wave == 0) {  // layer 8: signed sums  nz - 2m  resp.  z - 2m  = -q
     int t0, t1;
-    const int sc = (int)(int16_t)(-ternary_q<ARITH, 8>(r8, lane, x7[0], x7[1], t0, t1));
+    const int sc = (int)(int16_t)(-ternary_q<ARITH, 8, TWO>(r8, lane, x7[0], x7[1], t0, t1));
     if (scores) scores[(size_t)img * 64 + lane] = (int16_t)sc;
     if (classes) {
       int key = (lane < number_class && sc > 0) ? sc * 64 + (63 - lane) : -1;
@@ -1273,7 +1348,8 @@ inline dim3 grid_for(long long items, int groups) {  // matches map_block()
     if (ev) (void)hipEventRecord((ev)[i], stream);       \
   } while (0)
 
-template <int ARITH, bool OUT2>
+// TWO: the -2-aware instantiations of the 2-bit-weight kernels (see two_extra)
+template <int ARITH, bool OUT2, bool TWO = false>
 void run_cnv_t(const CnvLaunch &a) {
   const long long n = a.n, narrow_limit = kNarrowLimitCnv;
   uint32_t *A = reinterpret_cast<uint32_t *>(a.buf0), *B = reinterpret_cast<uint32_t *>(a.buf1);
@@ -1323,37 +1399,37 @@ void run_cnv_t(const CnvLaunch &a) {
   } else {
     const bool pix = n <= kPixelLaneMax;  // tiny batches: a lane per output pixel (see the XNOR branch)
     if (a.last_stage >= 1) {
-      if (pix) BNN_LAUNCH((k_vec<ARITH, 9, OUT2, true, 1, 30, 8, true>), grid_for(n * 784, 8), s, A64, B, a.rows[1], (int)(n * 784), 8, 1);
-      else BNN_STAGE((k_quad<ARITH, 1, 30, true, OUT2>), (k_quad<ARITH, 1, 30, true, OUT2, 8>), n * 196, 2, A64, B, a.rows[1]);
+      if (pix) BNN_LAUNCH((k_vec<ARITH, 9, OUT2, true, 1, 30, 8, true, TWO>), grid_for(n * 784, 8), s, A64, B, a.rows[1], (int)(n * 784), 8, 1);
+      else BNN_STAGE((k_quad<ARITH, 1, 30, true, OUT2, 32, TWO>), (k_quad<ARITH, 1, 30, true, OUT2, 8, TWO>), n * 196, 2, A64, B, a.rows[1]);
     }
     BNN_MARK(a.events, 2, s);
     if (a.last_stage >= 2) {
-      if (pix) BNN_LAUNCH((k_vec<ARITH, 9, OUT2, true, 1, 14, 8>), grid_for(n * 144, 16), s, B64, A, a.rows[2], (int)(n * 144), 16, 1);
-      else BNN_STAGE((k_quad<ARITH, 1, 14, false, OUT2>), (k_quad<ARITH, 1, 14, false, OUT2, 8>), n * 36, 4, B64, A, a.rows[2]);
+      if (pix) BNN_LAUNCH((k_vec<ARITH, 9, OUT2, true, 1, 14, 8, false, TWO>), grid_for(n * 144, 16), s, B64, A, a.rows[2], (int)(n * 144), 16, 1);
+      else BNN_STAGE((k_quad<ARITH, 1, 14, false, OUT2, 32, TWO>), (k_quad<ARITH, 1, 14, false, OUT2, 8, TWO>), n * 36, 4, B64, A, a.rows[2]);
     }
     BNN_MARK(a.events, 3, s);
     if (a.last_stage >= 3) {
-      if (pix) BNN_LAUNCH((k_vec<ARITH, 18, OUT2, true, 2, 12, 8, true>), grid_for(n * 100, 16), s, A64, B, a.rows[3], (int)(n * 100), 16, 1);
-      else BNN_STAGE((k_quad<ARITH, 2, 12, true, OUT2>), (k_quad<ARITH, 2, 12, true, OUT2, 8>), n * 25, 4, A64, B, a.rows[3]);
+      if (pix) BNN_LAUNCH((k_vec<ARITH, 18, OUT2, true, 2, 12, 8, true, TWO>), grid_for(n * 100, 16), s, A64, B, a.rows[3], (int)(n * 100), 16, 1);
+      else BNN_STAGE((k_quad<ARITH, 2, 12, true, OUT2, 32, TWO>), (k_quad<ARITH, 2, 12, true, OUT2, 8, TWO>), n * 25, 4, A64, B, a.rows[3]);
     }
     BNN_MARK(a.events, 4, s);
     if (n <= kCnvTailMax && !a.events && a.last_stage >= kCnvStages - 1) {
-      hipLaunchKernelGGL(k_cnv_tail_a2<ARITH>, dim3((unsigned)n), dim3(512), 0, s, B64, a.scores, a.classes, a.rows[4], a.rows[5],
+      hipLaunchKernelGGL((k_cnv_tail_a2<ARITH, TWO>), dim3((unsigned)n), dim3(512), 0, s, B64, a.scores, a.classes, a.rows[4], a.rows[5],
                          a.rows[6], a.rows[7], a.rows[8], a.number_class);
       return;
     }
-    if (a.last_stage >= 4) BNN_STAGE((k_vec<ARITH, 18, OUT2, true, 2, 5>), (k_vec<ARITH, 18, OUT2, true, 2, 5, 8>), n * 9, 8, B64, A, a.rows[4]);
+    if (a.last_stage >= 4) BNN_STAGE((k_vec<ARITH, 18, OUT2, true, 2, 5, 32, false, TWO>), (k_vec<ARITH, 18, OUT2, true, 2, 5, 8, false, TWO>), n * 9, 8, B64, A, a.rows[4]);
     BNN_MARK(a.events, 5, s);
-    if (a.last_stage >= 5) BNN_STAGE((k_vec<ARITH, 36, OUT2, false, 1, 1>), (k_vec<ARITH, 36, OUT2, false, 1, 1, 8>), n, 8, A64, B, a.rows[5]);
+    if (a.last_stage >= 5) BNN_STAGE((k_vec<ARITH, 36, OUT2, false, 1, 1, 32, false, TWO>), (k_vec<ARITH, 36, OUT2, false, 1, 1, 8, false, TWO>), n, 8, A64, B, a.rows[5]);
     BNN_MARK(a.events, 6, s);
-    if (a.last_stage >= 6) BNN_STAGE((k_vec<ARITH, 4, OUT2, false, 1, 1>), (k_vec<ARITH, 4, OUT2, false, 1, 1, 8>), n, 16, B64, A, a.rows[6]);
+    if (a.last_stage >= 6) BNN_STAGE((k_vec<ARITH, 4, OUT2, false, 1, 1, 32, false, TWO>), (k_vec<ARITH, 4, OUT2, false, 1, 1, 8, false, TWO>), n, 16, B64, A, a.rows[6]);
     BNN_MARK(a.events, 7, s);
-    if (a.last_stage >= 7) BNN_STAGE((k_vec<ARITH, 8, OUT2, false, 1, 1>), (k_vec<ARITH, 8, OUT2, false, 1, 1, 8>), n, 16, A64, B, a.rows[7]);
+    if (a.last_stage >= 7) BNN_STAGE((k_vec<ARITH, 8, OUT2, false, 1, 1, 32, false, TWO>), (k_vec<ARITH, 8, OUT2, false, 1, 1, 8, false, TWO>), n, 16, A64, B, a.rows[7]);
     BNN_MARK(a.events, 8, s);
   }
   if (a.last_stage >= 8) {
-    if (n <= kFcLastWaveMax) BNN_LAUNCH((k_fclast_wave<ARITH, 8>), dim3((unsigned)((n + 3) / 4)), s, B64, a.scores, a.classes, a.rows[8], (int)n, a.number_class);
-    else BNN_LAUNCH((k_fclast<ARITH, 8>), grid_for(n, 1), s, B64, a.scores, a.classes, a.rows[8], (int)n, a.number_class);
+    if (n <= kFcLastWaveMax) BNN_LAUNCH((k_fclast_wave<ARITH, 8, TWO>), dim3((unsigned)((n + 3) / 4)), s, B64, a.scores, a.classes, a.rows[8], (int)n, a.number_class);
+    else BNN_LAUNCH((k_fclast<ARITH, 8, TWO>), grid_for(n, 1), s, B64, a.scores, a.classes, a.rows[8], (int)n, a.number_class);
   }
   BNN_MARK(a.events, 9, s);
 }
@@ -1396,7 +1472,10 @@ hipError_t run_cnv(NetId net, const CnvLaunch &a) {
   switch (net) {
     case NET_CNVW1A1: run_cnv_t<AR_XNOR, false>(a); break;
     case NET_CNVW1A2: run_cnv_t<AR_TB, true>(a); break;
-    case NET_CNVW2A2: run_cnv_t<AR_TT, true>(a); break;
+    case NET_CNVW2A2:
+      if (a.has_two) run_cnv_t<AR_TT, true, true>(a);
+      else run_cnv_t<AR_TT, true>(a);
+      break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();

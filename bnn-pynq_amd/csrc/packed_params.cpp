@@ -74,6 +74,22 @@ void fill_row(const LayerSpec &L, const LayerView &F, int n, uint32_t *row, uint
           const int wv = F.weight(n, (ky * 3 + kx) * 3 + c);
           row[2 + tau / 4] |= (uint32_t)(uint8_t)(int8_t)wv << (8 * (tau % 4));
         }
+  } else if (L.wbits == 1) {
+    // 1-bit weights: the row's MW raw bits (1 <=> +1) are the low SIMD bits of its SF memory words, in
+    // order -- concatenate them instead of asking for one weight at a time
+    uint64_t *wq = reinterpret_cast<uint64_t *>(row + 2);
+    const int pe = n % L.fold.pe, nf = n / L.fold.pe, simd = L.fold.simd;
+    const int sf_count = L.fold.wmem / L.fold.tmem;
+    const uint64_t mask = simd >= 64 ? ~0ull : ((1ull << simd) - 1);
+    const uint64_t *words = (*F.w)[pe].data() + (size_t)nf * sf_count;
+    int bit = 0;
+    for (int sf = 0; sf < sf_count; sf++, bit += simd) {
+      const uint64_t v = words[sf] & mask;
+      wq[bit >> 6] |= v << (bit & 63);
+      if ((bit & 63) + simd > 64) wq[(bit >> 6) + 1] |= v >> (64 - (bit & 63));
+    }
+    if (L.arith == AR_TB)  // stored as the "weight is -1" plane
+      for (int k = 0; k < MW / 64; k++) wq[k] = ~wq[k];
   } else {
     uint64_t *wq = reinterpret_cast<uint64_t *>(row + 2);
     const int kw = MW / 64;
@@ -88,6 +104,22 @@ void fill_row(const LayerSpec &L, const LayerView &F, int n, uint32_t *row, uint
       if (L.arith == AR_XNOR) wq[k] = pos;
       else if (L.arith == AR_TB) wq[k] = neg;
       else { wq[2 * k] = neg; wq[2 * k + 1] = nz; }
+    }
+    if (L.arith == AR_TT) {
+      // ap_int<2> also has the value -2 (field 0b10).  No shipped parameter set uses it, but a bit flip
+      // makes one out of a 0 or a -1, and the reference then multiplies by -2.  Such columns are marked in
+      // a third plane behind the two others; the kernels evaluate the row as if the weight were -1 and,
+      // only when the row's flag is set, add the missing -a_j of every marked column.
+      uint64_t *two = wq + 2 * kw;
+      uint32_t any = 0;
+      for (int k = 0; k < kw; k++) {
+        uint64_t t = 0;
+        for (int b = 0; b < 64; b++)
+          if (F.weight(n, k * 64 + b) == -2) t |= 1ull << b;
+        two[k] = t;
+        any |= t != 0;
+      }
+      row[2 + 6 * kw] = any;
     }
   }
 }
@@ -143,7 +175,7 @@ uint32_t row_dwords_for(const LayerSpec &L) {
     case AR_INT8: return 12;
     case AR_XNOR: return 2 + 2 * kw;
     case AR_TB: return 2 + 2 * kw;
-    case AR_TT: return 2 + 4 * kw;
+    case AR_TT: return 4 + 6 * kw;  // t0, t1, (sign, non-zero) planes, "weight is -2" plane, flag, pad
   }
   return 0;
 }
@@ -162,6 +194,21 @@ std::string read_raw_params(const NetSpec &net, const std::string &dir, RawParam
     }
   }
   return "";
+}
+
+// rows of the 2-bit-weight layers that hold a weight of -2 (their flag dword, see fill_row): the runtime
+// launches the -2-aware kernel variants only while this is non-zero
+int count_two_rows(const NetSpec &net, const std::vector<uint8_t> &blob) {
+  PackedHeader h;
+  std::memcpy(&h, blob.data(), sizeof(h));
+  int count = 0;
+  for (int l = 0; l < net.nlayers; l++) {
+    if (net.L[l].arith != AR_TT) continue;
+    const uint32_t rd = h.layer[l].row_dwords, kw = h.layer[l].kw;
+    const uint32_t *rows = reinterpret_cast<const uint32_t *>(blob.data() + h.layer[l].offset);
+    for (uint32_t n = 0; n < h.layer[l].rows; n++) count += rows[(size_t)n * rd + 2 + 6 * kw] != 0;
+  }
+  return count;
 }
 
 void pack_blob(const NetSpec &net, const RawParams &raw, std::vector<uint8_t> &blob) {

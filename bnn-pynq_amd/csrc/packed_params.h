@@ -26,7 +26,8 @@
 //             signed form (lfcW1A2 L0): t_i = floor((MW - T_i + 1) / 2)   (T_i < MW - 2m)
 //   AR_TB     KW x u64, bit j = 1 <=> weight -1.  acc = nz(a) - 2*popcount(za & (sa ^ w))
 //             fire_i = T_i < acc
-//   AR_TT     KW x {u64 sign (1 <=> -1), u64 non-zero}.
+//   AR_TT     KW x {u64 sign (1 <=> -1), u64 non-zero}, then KW x u64 "weight is -2" (ap_int<2> 0b10: set by
+//             bit flips only; such a column is also set in both planes), a flag dword (any -2 in the row), a pad.
 //             acc = popcount(z) - 2*popcount(z & (sa ^ sw)),  z = za & zw;  fire_i = T_i < acc
 //
 // Column order j inside a row is the reference's: conv (ky*3+kx)*Cin + c, i.e.
@@ -44,7 +45,7 @@ namespace bnn {
 
 constexpr uint32_t kBlobMagic0 = 0x4D4E4E42u;  // "BNNM"
 constexpr uint32_t kBlobMagic1 = 0x35353349u;  // "I355"
-constexpr uint32_t kBlobVersion = 2;
+constexpr uint32_t kBlobVersion = 3;
 
 struct PackedLayer {
   uint32_t offset;      // bytes from blob start, 256-byte aligned
@@ -91,6 +92,9 @@ void repack_row(const NetSpec &net, const RawParams &raw, int l, int n, std::vec
 // foldedmv-offload.cpp:321-323).  Short files are zero-filled like the
 // reference's reader (foldedmv-offload.cpp:283-284).
 std::string pack_params_from_dir(const NetSpec &net, const std::string &dir, std::vector<uint8_t> &blob);
+
+// Number of rows (2-bit-weight layers only) holding a weight of -2, i.e. with their flag dword set.
+int count_two_rows(const NetSpec &net, const std::vector<uint8_t> &blob);
 
 // Sanity-check a blob received from elsewhere (e.g. an RCCL broadcast).
 std::string validate_blob(const NetSpec &net, const void *blob, size_t bytes);

@@ -65,6 +65,7 @@ struct Runtime {
   std::vector<Fault> last_faults;
   const uint32_t *rows[9] = {};
   const uint8_t *l0_mfma = nullptr;  // layer 0 as an MFMA operand (CNV nets), unless BNN_MI355X_L0=valu
+  int two_rows = 0;  // rows holding a weight of -2 (2-bit-weight net under fault injection): kernels.hip, two_extra
   // workspace
   int cap = 0;
   void *buf0 = nullptr, *buf1 = nullptr;
@@ -140,6 +141,7 @@ int upload_blob() {
   }
   HIP_OK(hipDeviceSynchronize());  // a reload (fault campaigns reload per run): nothing may still read the old rows
   HIP_OK(hipMemcpy(r.d_blob, r.blob.data(), r.blob.size(), hipMemcpyHostToDevice));
+  r.two_rows = count_two_rows(r.spec, r.blob);
   const PackedHeader *h = reinterpret_cast<const PackedHeader *>(r.blob.data());
   for (int l = 0; l < r.spec.nlayers; l++)
     r.rows[l] = reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(r.d_blob) + h->layer[l].offset);
@@ -255,6 +257,7 @@ int enqueue(const uint8_t *d_imgs, int n, int ncls, int32_t *d_classes, int16_t 
     a.images = d_imgs; a.n = n; a.buf0 = r.buf0; a.buf1 = r.buf1;
     for (int l = 0; l < 9; l++) a.rows[l] = r.rows[l];
     a.l0_mfma = r.l0_mfma;
+    a.has_two = r.two_rows > 0;
     a.scores = d_scores; a.classes = d_classes; a.number_class = ncls; a.stream = s; a.events = evs;
     a.last_stage = r.debug_last_stage >= 0 ? r.debug_last_stage : kCnvStages - 1;
     e = run_cnv(r.spec.id, a);
@@ -698,6 +701,7 @@ int *inference_multiple_with_faults(const char *path, int number_class, int *ima
         if (row < 0) continue;
         size_t off = 0, bytes = 0;
         repack_row(r.spec, r.raw, flt.layer, row, r.blob, &off, &bytes);
+        if (r.spec.L[flt.layer].arith == AR_TT) r.two_rows = count_two_rows(r.spec, r.blob);
         patches.emplace_back(r.blob.begin() + off, r.blob.begin() + off + bytes);
         HIP_OK(hipMemcpyAsync(static_cast<uint8_t *>(r.d_blob) + off, patches.back().data(), bytes, hipMemcpyHostToDevice, r.stream));
       }

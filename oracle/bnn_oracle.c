@@ -56,6 +56,7 @@ struct bnn_oracle {
   /* fast path: bit planes, [mh][kw] */
   uint64_t *Wp[9];  /* 1-bit: bit=1 <=> +1 ; 2-bit: sign plane (bit=1 <=> -1) */
   uint64_t *Wn[9];  /* 2-bit: non-zero plane */
+  uint64_t *Wt[9];  /* 2-bit: columns whose weight is -2 (ap_int<2> 0b10: reachable by bit flips only) */
   /* the PE memories as the files hold them, [pe][wmem] / [pe][tmem*nthr] (DoMemInit's targets,
    * top.cpp:78-135): kept so that single words can be modified (fault injection) */
   uint64_t *wraw[9], *traw[9];
@@ -204,7 +205,7 @@ static void derive_row(bnn_oracle *o, int l, int n) {
     }
     o->T[l][n * 2 + i] = t;
   }
-  for (int k = 0; k < kw; k++) o->Wp[l][(size_t)n * kw + k] = o->Wn[l][(size_t)n * kw + k] = 0;
+  for (int k = 0; k < kw; k++) o->Wp[l][(size_t)n * kw + k] = o->Wn[l][(size_t)n * kw + k] = o->Wt[l][(size_t)n * kw + k] = 0;
   for (int j = 0; j < L->mw; j++) {
     const int v = o->W[l][(size_t)n * L->mw + j];
     const uint64_t b = (uint64_t)1 << (j & 63);
@@ -213,6 +214,7 @@ static void derive_row(bnn_oracle *o, int l, int n) {
     } else {
       if (v < 0) o->Wp[l][(size_t)n * kw + j / 64] |= b; /* sign plane */
       if (v != 0) o->Wn[l][(size_t)n * kw + j / 64] |= b;
+      if (v == -2) o->Wt[l][(size_t)n * kw + j / 64] |= b;
     }
   }
 }
@@ -227,6 +229,7 @@ static int load_layer(bnn_oracle *o, const char *dir, int l) {
   o->T[l] = (int32_t *)calloc((size_t)L->mh * 2, sizeof(int32_t));
   o->Wp[l] = (uint64_t *)calloc((size_t)L->mh * kw, 8);
   o->Wn[l] = (uint64_t *)calloc((size_t)L->mh * kw, 8);
+  o->Wt[l] = (uint64_t *)calloc((size_t)L->mh * kw, 8);
   for (int p = 0; p < L->pe; p++) {
     snprintf(path, sizeof(path), "%s/%d-%d-weights.bin", dir, l, p);
     if (read_words(path, o->wraw[l] + (size_t)p * L->wmem, (size_t)L->wmem)) {
@@ -304,7 +307,7 @@ bnn_oracle *bnn_oracle_create(const char *network, const char *param_dir) {
 void bnn_oracle_destroy(bnn_oracle *o) {
   if (!o) return;
   for (int l = 0; l < 9; l++) {
-    free(o->W[l]); free(o->T[l]); free(o->Wp[l]); free(o->Wn[l]); free(o->wraw[l]); free(o->traw[l]);
+    free(o->W[l]); free(o->T[l]); free(o->Wp[l]); free(o->Wn[l]); free(o->Wt[l]); free(o->wraw[l]); free(o->traw[l]);
   }
   free(o);
 }
@@ -506,7 +509,7 @@ static inline int pc64(uint64_t x) { return __builtin_popcountll(x); }
 typedef struct { uint64_t *s, *z; } planes; /* xnor nets use only s (= P) */
 
 /* one neuron over kw words of (gathered) input */
-static inline int32_t dot_fast(const lcfg *L, const uint64_t *wp, const uint64_t *wn,
+static inline int32_t dot_fast(const lcfg *L, const uint64_t *wp, const uint64_t *wn, const uint64_t *wt,
                                const uint64_t *as, const uint64_t *az, int kw) {
   int32_t acc = 0;
   if (L->xnor) {
@@ -519,6 +522,11 @@ static inline int32_t dot_fast(const lcfg *L, const uint64_t *wp, const uint64_t
       neg += pc64(nz & (wp[k] ^ as[k]));
     }
     acc = nzc - 2 * neg;
+    /* a weight of -2 sits in both planes and has been counted as -1: the other -a_j */
+    for (int k = 0; k < kw; k++) {
+      const uint64_t x = wt[k] & az[k];
+      acc += 2 * pc64(x & as[k]) - pc64(x);
+    }
   }
   return acc;
 }
@@ -595,7 +603,7 @@ static void cnv_one_fast(const bnn_oracle *o, const uint8_t *img, int16_t *score
                 colz[(ky * 3 + kx) * cw + k] = cz[((oy + ky) * D + ox + kx) * cw + k];
               }
           for (int n = 0; n < L->mh; n++) {
-            const int32_t acc = dot_fast(L, o->Wp[l] + (size_t)n * kw, o->Wn[l] + (size_t)n * kw,
+            const int32_t acc = dot_fast(L, o->Wp[l] + (size_t)n * kw, o->Wn[l] + (size_t)n * kw, o->Wt[l] + (size_t)n * kw,
                                          cols, colz, kw);
             act_store(o, l, n, acc, ns + (oy * OD + ox) * ow, nz + (oy * OD + ox) * ow);
           }
@@ -623,13 +631,13 @@ static void cnv_one_fast(const bnn_oracle *o, const uint8_t *img, int16_t *score
       memset(ns, 0, (size_t)(L->mh / 64) * 8);
       memset(nz, 0, (size_t)(L->mh / 64) * 8);
       for (int n = 0; n < L->mh; n++) {
-        const int32_t acc = dot_fast(L, o->Wp[l] + (size_t)n * kw, o->Wn[l] + (size_t)n * kw, cs, cz, kw);
+        const int32_t acc = dot_fast(L, o->Wp[l] + (size_t)n * kw, o->Wn[l] + (size_t)n * kw, o->Wt[l] + (size_t)n * kw, cs, cz, kw);
         act_store(o, l, n, acc, ns, nz);
       }
       { uint64_t *t = cs; cs = ns; ns = t; t = cz; cz = nz; nz = t; }
     } else {
       for (int n = 0; n < 64; n++) {
-        const int32_t acc = dot_fast(L, o->Wp[l] + (size_t)n * kw, o->Wn[l] + (size_t)n * kw, cs, cz, kw);
+        const int32_t acc = dot_fast(L, o->Wp[l] + (size_t)n * kw, o->Wn[l] + (size_t)n * kw, o->Wt[l] + (size_t)n * kw, cs, cz, kw);
         scores[n] = (int16_t)(uint16_t)(acc & 0xFFFF);
       }
     }
@@ -665,7 +673,7 @@ static uint64_t lfc_one_fast(const bnn_oracle *o, const uint8_t *px) {
     memset(ns, 0, 16 * 8);
     memset(nz, 0, 16 * 8);
     for (int n = 0; n < L->mh; n++) {
-      const int32_t acc = dot_fast(L, o->Wp[l] + (size_t)n * kw, o->Wn[l] + (size_t)n * kw, cs, cz, kw);
+      const int32_t acc = dot_fast(L, o->Wp[l] + (size_t)n * kw, o->Wn[l] + (size_t)n * kw, o->Wt[l] + (size_t)n * kw, cs, cz, kw);
       act_store(o, l, n, acc, ns, nz);
     }
     { uint64_t *t = cs; cs = ns; ns = t; t = cz; cz = nz; nz = t; }

@@ -7,7 +7,8 @@ import numpy as np
 from bnn import params_io
 
 
-def make(directory, network, seed):
+def make(directory, network, seed, neg2=0.0):
+    """neg2: fraction of the 2-bit weight fields set to -2 (0b10), the value bit flips create"""
     rng = np.random.default_rng(seed)
     cnv = network.startswith("cnv")
     a2 = network.endswith("A2")
@@ -17,7 +18,7 @@ def make(directory, network, seed):
         if L["wbits"] == 1:
             W = rng.choice(np.array([-1, 1], np.int8), size=(mh, mw))
         else:
-            W = rng.choice(np.array([-1, 0, 1], np.int8), size=(mh, mw), p=[0.35, 0.3, 0.35])
+            W = rng.choice(np.array([-1, 0, 1, -2], np.int8), size=(mh, mw), p=[0.35 - neg2 / 2, 0.3 - neg2 / 2, 0.35, neg2])
         nthr = max(L["nthr"], 1)
         if cnv and l == 0:
             centre, spread, lo, hi = 0.0, 1800.0, -(1 << 23), (1 << 23) - 1     # 2*sum(+-q), 2^-8 units

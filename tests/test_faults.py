@@ -81,8 +81,10 @@ def test_faulty_blob_matches_oracle_memories(network, dataset):
             bits = lambda x: np.unpackbits(np.ascontiguousarray(x).view(np.uint8), bitorder="little").astype(np.int8)
             if network.endswith("A1") or (network == "lfcW1A2" and l == 0):
                 assert (bits(wq) == (W > 0)).all()
-            elif "W2" in network:
-                assert (bits(wq[0::2]) == (W < 0)).all() and (bits(wq[1::2]) == (W != 0)).all()
+            elif "W2" in network:   # {sign, non-zero} plane pairs, then the "weight is -2" plane, flag, pad
+                pairs, two, flag = wq[: 2 * kw], wq[2 * kw: 3 * kw], R[2 + 6 * kw]
+                assert (bits(pairs[0::2]) == (W < 0)).all() and (bits(pairs[1::2]) == (W != 0)).all()
+                assert (bits(two) == (W == -2)).all() and flag == int((W == -2).any())
             else:
                 assert (bits(wq) == (W < 0)).all()
     # rows no fault touched are byte-identical to the clean blob (the matrix-pipe copy of layer 0

@@ -69,3 +69,14 @@ def test_every_stage_random_params(network, dataset, tmp_path):
     random_params.make(str(tmp_path), network, 9)
     check_all_stages(network, str(tmp_path), 42)
     gl.load(network).load_parameters(gl.param_dir(dataset, network).encode())   # leave the library as found
+
+
+def test_every_stage_with_weights_of_minus_two(tmp_path):
+    """cnvW2A2 with 4 % of the 2-bit weight fields = 0b10 (-2): the value a bit flip makes out of a 0 or a -1;
+    the reference multiplies by it (ap_int<2>), so must every stage -- checked against the FAITHFUL scalar
+    restatement, which uses the integer weights"""
+    import random_params
+    W, _ = random_params.make(str(tmp_path), "cnvW2A2", 12, neg2=0.04)
+    assert all((w == -2).any() for w in W)
+    check_all_stages("cnvW2A2", str(tmp_path), 43)
+    gl.load("cnvW2A2").load_parameters(gl.param_dir("cifar10", "cnvW2A2").encode())

@@ -106,6 +106,28 @@ def test_random_params_bit_exact(network, seed, tmp_path):
     assert np.unique(ref).size > 8
 
 
+def test_weights_of_minus_two_all_paths(tmp_path):
+    """cnvW2A2 rows holding the weight -2 (fault-injection territory): small batch (pixel lanes + one-launch
+    tail), mid batch (quad kernels, 8-neuron form) and a wide batch, raw scores against the oracle -- whose
+    fast path is itself checked against the faithful one in test_oracle_selfcheck.py"""
+    import random_params
+    random_params.make(str(tmp_path), "cnvW2A2", 5, neg2=0.03)
+    L = gl.load("cnvW2A2")
+    L.load_parameters(str(tmp_path).encode())
+    assert L.bnn_mi355x_last_error() == b""
+    _nets.pop("cnvW2A2", None)
+    net = gl.Net.__new__(gl.Net)
+    net.L, net.network, net.is_cnv, net.isz = L, "cnvW2A2", True, 3072
+    o = ol.Oracle("cnvW2A2", str(tmp_path))
+    for n in (3, 700, 1500, 20000):
+        imgs = rand_images("cnvW2A2", n, n)
+        got = net.raw(imgs)
+        pick = np.arange(n) if n <= 1500 else np.random.default_rng(1).choice(n, 400, replace=False)
+        assert (got[pick] == o.scores_fast(imgs[pick])).all(), n
+    assert (net.raw(imgs[:2])[0] == o.scores_ref(imgs[0])).all()          # and the faithful scalar path
+    L.load_parameters(gl.param_dir("cifar10", "cnvW2A2").encode())
+
+
 def test_detail_scores():
     ncls = 10
     imgs = rand_images("cnvW1A1", 77, 3)

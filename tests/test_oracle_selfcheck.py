@@ -80,3 +80,19 @@ def test_short_param_files_are_zero_filled():
     W = o.weights(8)
     assert W.shape == (64, 512)
     assert (W[12:] == -1).all() and (W[:12] != -1).any()
+
+
+def test_fast_path_handles_weights_of_minus_two(tmp_path):
+    """ap_int<2> weights can be -2 (0b10) once bits are flipped: the plane-based fast path must agree with the
+    faithful scalar path, which multiplies by the integer weight (cnvW2A2/hw/top.cpp:52-60)"""
+    import sys
+    sys.path.insert(0, os.path.join(ol.ROOT, "bnn-pynq_amd"))
+    import random_params
+    W, _ = random_params.make(str(tmp_path), "cnvW2A2", 21, neg2=0.05)
+    assert sum(int((w == -2).sum()) for w in W) > 1000
+    o = ol.Oracle("cnvW2A2", str(tmp_path))
+    assert (o.weights(1) == W[1]).all()                      # the loader decodes 0b10 as -2
+    imgs = np.random.default_rng(2).integers(0, 256, (3, 3072), dtype=np.uint8)
+    fast = o.scores_fast(imgs)
+    for i in range(3):
+        assert (fast[i] == o.scores_ref(imgs[i])).all()

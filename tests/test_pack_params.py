@@ -36,7 +36,7 @@ def test_blob_matches_oracle_weights(network, dataset):
     blob = gl.pack_params(network, gl.param_dir(dataset, network))
     o = ol.Oracle(network, ol.param_dir(dataset, network))
     magic0, magic1, version, net_id, nlayers, total, _, _ = struct.unpack_from("<8I", blob, 0)
-    assert (magic0, magic1, version) == (0x4D4E4E42, 0x35353349, 2)
+    assert (magic0, magic1, version) == (0x4D4E4E42, 0x35353349, 3)
     assert total == blob.size and nlayers == o.nl
     for l in range(nlayers):
         off, rd, rows, kw = struct.unpack_from("<4I", blob, 32 + 16 * l)
@@ -59,9 +59,12 @@ def test_blob_matches_oracle_weights(network, dataset):
                 assert (bits(wq) == (W > 0)).all()
             elif ar == AR_TB:
                 assert (W != 0).all() and (bits(wq) == (W < 0)).all()
-            else:
-                assert (bits(np.ascontiguousarray(wq[:, 0::2])) == (W < 0)).all()
-                assert (bits(np.ascontiguousarray(wq[:, 1::2])) == (W != 0)).all()
+            else:   # {sign, non-zero} plane pairs, the "weight is -2" plane (empty in trained sets), flag, pad
+                assert rd == 4 + 6 * kw
+                pairs = wq[:, : 2 * kw]
+                assert (bits(np.ascontiguousarray(pairs[:, 0::2])) == (W < 0)).all()
+                assert (bits(np.ascontiguousarray(pairs[:, 1::2])) == (W != 0)).all()
+                assert (wq[:, 2 * kw:] == 0).all() and not (W == -2).any()
         # thresholds: check the pre-transformed form against its definition
         L = o.L
         t = R[:, :2].astype(np.uint32).view(np.int32)
