@@ -986,10 +986,11 @@ __global__ __launch_bounds__(512) void k_cnv_tail(const uint64_t *__restrict__ i
   }
 }
 
+// (Not used while cnvW2A2 holds weights of -2: those runs take the staged, -2-aware kernels.)
 // The same for the 2-bit nets (cnvW1A2: AR_TB, cnvW2A2: AR_TT): activations are (sign, non-zero) plane
 // pairs, a layer's output planes come from the two ballots of a wave (fire_i <=> q + t_i < 0 with
 // q = 2m - nz resp. 2m - z, see k_quad), layer 8 yields the signed sums.
-template <int ARITH, int KW, bool TWO>
+template <int ARITH, int KW>
 __device__ __forceinline__ int ternary_q(const uint32_t *__restrict__ rows, int n, const uint64_t *sa, const uint64_t *za, int &t0, int &t1) {
   constexpr int ROW_DW = row_dw<ARITH, KW>();
   const uint32_t *__restrict__ r = rows + (size_t)n * ROW_DW;
@@ -1008,16 +1009,10 @@ __device__ __forceinline__ int ternary_q(const uint32_t *__restrict__ rows, int 
       m += pc64(zz & (sa[k] ^ w[2 * k]));
     }
   }
-  if constexpr (TWO) {
-    if (r[2 + 6 * KW]) {  // weights of -2 in this row (fault injection only); thread = neuron: a per-lane branch
-#pragma unroll
-      for (int k = 0; k < KW; k++) z += two_extra64(w[2 * KW + k], sa[k], za[k]);
-    }
-  }
   return 2 * m - z;
 }
 
-template <int ARITH, bool TWO = false>
+template <int ARITH>
 __global__ __launch_bounds__(512) void k_cnv_tail_a2(const uint64_t *__restrict__ in, int16_t *__restrict__ scores,
                                                       int32_t *__restrict__ classes, const uint32_t *__restrict__ r4,
                                                       const uint32_t *__restrict__ r5, const uint32_t *__restrict__ r6,
@@ -1033,8 +1028,6 @@ __global__ __launch_bounds__(512) void k_cnv_tail_a2(const uint64_t *__restrict_
     const uint32_t *__restrict__ r = r4 + (size_t)n * ROW_DW;
     const uint64_t *__restrict__ w = reinterpret_cast<const uint64_t *>(r + 2);
     const int t0 = (int)r[0], t1 = (int)r[1];
-    bool has_two = false;  // weights of -2 in this row (fault injection only)
-    if constexpr (TWO) has_two = r[2 + 6 * 18] != 0;
     for (int p = (t >> 8); p < 9; p += 2) {
       const int oy = p / 3, ox = p - oy * 3;
       int m = 0, z = 0;
@@ -1055,12 +1048,6 @@ __global__ __launch_bounds__(512) void k_cnv_tail_a2(const uint64_t *__restrict_
               m += pc64(zz & (sa ^ w[2 * j]));
             }
           }
-      if (has_two) {  // kept out of the loop above: the fault-free path must not carry these loads
-        for (int j = 0; j < 18; j++) {
-          const int tap = j >> 1, a = ((oy + tap / 3) * 5 + ox + tap % 3) * 2 + (j & 1);
-          z += two_extra64(w[2 * 18 + j], x3[0][a], x3[1][a]);
-        }
-      }
       const int q = 2 * m - z;
       const uint64_t f0 = __ballot(q + t0 < 0), f1 = __ballot(q + t1 < 0);
       if (lane == 0) { x4[0][p * 4 + (wave & 3)] = ~(f0 | f1); x4[1][p * 4 + (wave & 3)] = ~(f0 ^ f1); }
@@ -1069,28 +1056,28 @@ __global__ __launch_bounds__(512) void k_cnv_tail_a2(const uint64_t *__restrict_
   __syncthreads();
   if (t < 256) {  // layer 5
     int t0, t1;
-    const int q = ternary_q<ARITH, 36, TWO>(r5, t, x4[0], x4[1], t0, t1);
+    const int q = ternary_q<ARITH, 36>(r5, t, x4[0], x4[1], t0, t1);
     const uint64_t f0 = __ballot(q + t0 < 0), f1 = __ballot(q + t1 < 0);
     if (lane == 0) { x5[0][wave] = ~(f0 | f1); x5[1][wave] = ~(f0 ^ f1); }
   }
   __syncthreads();
   {  // layer 6
     int t0, t1;
-    const int q = ternary_q<ARITH, 4, TWO>(r6, t, x5[0], x5[1], t0, t1);
+    const int q = ternary_q<ARITH, 4>(r6, t, x5[0], x5[1], t0, t1);
     const uint64_t f0 = __ballot(q + t0 < 0), f1 = __ballot(q + t1 < 0);
     if (lane == 0) { x6[0][wave] = ~(f0 | f1); x6[1][wave] = ~(f0 ^ f1); }
   }
   __syncthreads();
   {  // layer 7
     int t0, t1;
-    const int q = ternary_q<ARITH, 8, TWO>(r7, t, x6[0], x6[1], t0, t1);
+    const int q = ternary_q<ARITH, 8>(r7, t, x6[0], x6[1], t0, t1);
     const uint64_t f0 = __ballot(q + t0 < 0), f1 = __ballot(q + t1 < 0);
     if (lane == 0) { x7[0][wave] = ~(f0 | f1); x7[1][wave] = ~(f0 ^ f1); }
   }
   __syncthreads();
   if (wave == 0) {  // layer 8: signed sums  nz - 2m  resp.  z - 2m  = -q
     int t0, t1;
-    const int sc = (int)(int16_t)(-ternary_q<ARITH, 8, TWO>(r8, lane, x7[0], x7[1], t0, t1));
+    const int sc = (int)(int16_t)(-ternary_q<ARITH, 8>(r8, lane, x7[0], x7[1], t0, t1));
     if (scores) scores[(size_t)img * 64 + lane] = (int16_t)sc;
     if (classes) {
       int key = (lane < number_class && sc > 0) ? sc * 64 + (63 - lane) : -1;
@@ -1413,10 +1400,12 @@ void run_cnv_t(const CnvLaunch &a) {
       else BNN_STAGE((k_quad<ARITH, 2, 12, true, OUT2, 32, TWO>), (k_quad<ARITH, 2, 12, true, OUT2, 8, TWO>), n * 25, 4, A64, B, a.rows[3]);
     }
     BNN_MARK(a.events, 4, s);
-    if (n <= kCnvTailMax && !a.events && a.last_stage >= kCnvStages - 1) {
-      hipLaunchKernelGGL((k_cnv_tail_a2<ARITH, TWO>), dim3((unsigned)n), dim3(512), 0, s, B64, a.scores, a.classes, a.rows[4], a.rows[5],
-                         a.rows[6], a.rows[7], a.rows[8], a.number_class);
-      return;
+    if constexpr (!TWO) {  // (the -2-aware variant of this kernel would spill: such runs take the staged layers)
+      if (n <= kCnvTailMax && !a.events && a.last_stage >= kCnvStages - 1) {
+        hipLaunchKernelGGL((k_cnv_tail_a2<ARITH>), dim3((unsigned)n), dim3(512), 0, s, B64, a.scores, a.classes, a.rows[4], a.rows[5],
+                           a.rows[6], a.rows[7], a.rows[8], a.number_class);
+        return;
+      }
     }
     if (a.last_stage >= 4) BNN_STAGE((k_vec<ARITH, 18, OUT2, true, 2, 5, 32, false, TWO>), (k_vec<ARITH, 18, OUT2, true, 2, 5, 8, false, TWO>), n * 9, 8, B64, A, a.rows[4]);
     BNN_MARK(a.events, 5, s);
