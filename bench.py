@@ -48,15 +48,16 @@ def host_cores():
 # algorithmic bytes per image of the fused path: 3072 in + 4 out
 ALG_BYTES = {"cnv": 3072 + 4, "lfc": 784 + 4}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# Integer-pipe issue floor (measured in profiles/r01_microbench*.txt): a wave64
-# v_xor/v_bitop3 + v_bcnt pair (32 synapses per lane) sustains 6.6 SIMD-cycles; v_dot4c and every other
-# VOP3 / SGPR-operand integer op 4.2; 1024 SIMDs; 2.38 GHz held under this load.
-PAIR_CYC, SLOT_CYC, N_SIMD, CLK_HZ = 6.6, 4.2, 1024, 2.38e9
+# Integer-pipe issue floor (measured in profiles/r01_microbench*.txt): the best schedule found
+# for a wave64 logic-op + v_bcnt pair (32 synapses per lane) -- the pair followed by one s_nop 0 -- sustains
+# 6.3 SIMD-cycles (6.25..6.40 over runs; v_bitop3 pairs 6.6); v_dot4c and every other VOP3 / SGPR-operand
+# integer op 4.2; 1024 SIMDs; 2.38 GHz held under this load.
+PAIR_CYC, SLOT_CYC, N_SIMD, CLK_HZ = 6.3, 4.2, 1024, 2.38e9
 WORD_MACS = {"cnv": 905216, "lfc": 47104}          # 64-bit word-MACs per image, layers 1..
 PAIRS_PER_WORD = {"W1A1": 2, "W1A2": 2, "W2A2": 4}  # (logic op + v_bcnt) pairs per 64-bit word-MAC
-# measured pair rates (profiles/r01_microbench6/7): xor+bcnt and bitop3+bcnt 6.6; the W2A2 quad
-# (and, bcnt, bitop3 on the and's result, bcnt) 14.2 per 32 synapses = 7.1 per pair
-PAIR_CYC_OF = {"W1A1": PAIR_CYC, "W1A2": PAIR_CYC, "W2A2": 7.1}
+# measured (profiles/r01_microbench9_nop_cadence.txt): xor+bcnt 6.3, bitop3+bcnt 6.6, the W2A2 quad as two
+# such pairs 12.7 per 32 synapses
+PAIR_CYC_OF = {"W1A1": PAIR_CYC, "W1A2": 6.6, "W2A2": 6.35}
 
 
 def issue_floor_cycles(network):

@@ -353,7 +353,8 @@ __global__ __launch_bounds__(kBlock) void k_conv0_mfma(const uint8_t *__restrict
 // Measured on MI355X (profiles/r01_microbench*.txt): v_xor_b32 and
 // v_bcnt_u32_b32 both go down the integer pipe, ~4.2 cycles per wave64
 // instruction per SIMD for v_bcnt and for anything with an SGPR operand; an
-// alternating xor/bcnt stream sustains 6.6 cycles per 32-bit pair.  That pair
+// alternating xor/bcnt stream sustains 6.3 cycles per 32-bit pair when every pair is followed by one
+// s_nop 0 (which the compiler puts behind each of these asm statements; profiles/r01_microbench9).  That pair
 // rate IS the roofline of this path, so the kernels below spend integer-pipe
 // slots on nothing else:
 //   * every accumulator is one chain of v_bcnt (which adds for free); the empty
@@ -567,10 +568,15 @@ __device__ __forceinline__ void mac32(int &m, int &z, uint32_t as, uint32_t az, 
         : "=&v"(t0), "+v"(m)
         : "s"(wq[half]), "v"(as), "v"(az));
   } else {
-    asm("v_and_b32 %0, %4, %5\n\tv_bcnt_u32_b32 %2, %0, %2\n\t"
-        "v_bitop3_b32 %1, %6, %7, %0 bitop3:" BNN_BITOP_AND_XOR "\n\tv_bcnt_u32_b32 %3, %1, %3"
-        : "=&v"(t0), "=&v"(t1), "+v"(z), "+v"(m)
-        : "s"(wq[2 + half]), "v"(az), "s"(wq[half]), "v"(as));
+    // two statements, not one: the s_nop 0 the compiler puts behind every inline-asm statement is what lets
+    // the SIMD alternate between waves at the right cadence -- (op, bcnt, s_nop 0) issues in 6.3 cycles, the
+    // four instructions back to back in 14.2 instead of 12.7 (profiles/r01_microbench9_nop_cadence.txt)
+    asm("v_and_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "=&v"(t0), "+v"(z) : "s"(wq[2 + half]), "v"(az));
+    // (behind the first statement the compiler adds the s_nop itself -- the next one reads t0 --, behind the
+    // second it does not: written out)
+    asm("v_bitop3_b32 %0, %2, %3, %4 bitop3:" BNN_BITOP_AND_XOR "\n\tv_bcnt_u32_b32 %1, %0, %1\n\ts_nop 0"
+        : "=&v"(t1), "+v"(m)
+        : "s"(wq[half]), "v"(as), "v"(t0));
   }
 }
 
