@@ -391,9 +391,12 @@ __device__ __forceinline__ void xpop4(int &m0, int &m1, int &m2, int &m3, uint32
   xpop(m0, w, a0); xpop(m1, w, a1); xpop(m2, w, a2); xpop(m3, w, a3);
 #endif
 }
-__device__ __forceinline__ int xpop0(uint32_t w, uint32_t a) {
-  int acc = __builtin_popcount(w ^ a);
-  asm("" : "+v"(acc));
+// first pair of a chain: the accumulator starts at `seed` (an SGPR: -threshold, so that the chain ends on
+// m - t and the compare costs neither a v_mov 0 nor a subtract)
+__device__ __forceinline__ int xpop_seed(uint32_t w, uint32_t a, int seed) {
+  uint32_t t;
+  int acc;
+  asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %4" : "=&v"(t), "=v"(acc) : "s"(w), "v"(a), "s"(seed));
   return acc;
 }
 // result of one neuron group of one pixel/vector: a whole dword (32 neurons per block, the
@@ -431,21 +434,25 @@ __global__ __launch_bounds__(kBlock) void k_quad_x(const uint64_t *__restrict__ 
     uint32_t b[4] = {0, 0, 0, 0};
     for (int c = NPB - 1; c >= 0; c--) {
       kptr32 r = w + c * ROW_DW;
-      const int t = (int)r[0];
-      int m[2][2] = {{0, 0}, {0, 0}};
+      const int nt = -(int)r[0];  // (scalar) every chain starts at -t: it ends on m - t, whose sign is the decision
+      int m[2][2];
   #pragma unroll
       for (int j = 0; j < KW; j++) {
         const int ky = j / (3 * CW), kx = (j / CW) % 3, k = j % CW;
         const uint32_t w0 = r[2 + 2 * j], w1 = r[3 + 2 * j];
-        xpop4(m[0][0], m[0][1], m[1][0], m[1][1], w0, wl[ky][kx][k], wl[ky][kx + 1][k], wl[ky + 1][kx][k], wl[ky + 1][kx + 1][k]);
+        if (j == 0) {
+  #pragma unroll
+          for (int i = 0; i < 4; i++) m[i >> 1][i & 1] = xpop_seed(w0, wl[ky + (i >> 1)][kx + (i & 1)][k], nt);
+        } else {
+          xpop4(m[0][0], m[0][1], m[1][0], m[1][1], w0, wl[ky][kx][k], wl[ky][kx + 1][k], wl[ky + 1][kx][k], wl[ky + 1][kx + 1][k]);
+        }
         xpop4(m[0][0], m[0][1], m[1][0], m[1][1], w1, wh[ky][kx][k], wh[ky][kx + 1][k], wh[ky + 1][kx][k], wh[ky + 1][kx + 1][k]);
       }
-      if constexpr (POOL) {  // OR of the four fire bits == (min m) < t
-        const int mn = min(min(m[0][0], m[0][1]), min(m[1][0], m[1][1]));
-        b[0] = shift_in_sign(b[0], mn - t);
+      if constexpr (POOL) {  // OR of the four fire bits == (min (m - t)) < 0
+        b[0] = shift_in_sign(b[0], min(min(m[0][0], m[0][1]), min(m[1][0], m[1][1])));
       } else {
   #pragma unroll
-        for (int i = 0; i < 4; i++) b[i] = shift_in_sign(b[i], m[i >> 1][i & 1] - t);
+        for (int i = 0; i < 4; i++) b[i] = shift_in_sign(b[i], m[i >> 1][i & 1]);
       }
     }
     if constexpr (POOL) {
@@ -516,7 +523,7 @@ __global__ __launch_bounds__(kBlock) void k_vec_x(const uint64_t *__restrict__ i
     uint32_t b = 0;
     for (int c = NPB - 1; c >= 0; c -= 2) {
       kptr32 r1 = w + c * ROW_DW, r0 = r1 - ROW_DW;
-      int m1 = xpop0(r1[2], al[0]), m0 = xpop0(r0[2], al[0]);
+      int m1 = xpop_seed(r1[2], al[0], -(int)r1[0]), m0 = xpop_seed(r0[2], al[0], -(int)r0[0]);
       xpop(m1, r1[3], ah[0]);
       xpop(m0, r0[3], ah[0]);
   #pragma unroll
@@ -526,8 +533,8 @@ __global__ __launch_bounds__(kBlock) void k_vec_x(const uint64_t *__restrict__ i
         xpop(m1, r1[3 + 2 * k], ah[k]);
         xpop(m0, r0[3 + 2 * k], ah[k]);
       }
-      b = shift_in_sign(b, m1 - (int)r1[0]);
-      b = shift_in_sign(b, m0 - (int)r0[0]);
+      b = shift_in_sign(b, m1);
+      b = shift_in_sign(b, m0);
     }
     if constexpr (POOL) {
       b |= __shfl_xor(b, 1, 64);
