@@ -255,10 +255,10 @@ class CnvClassifier:
 
     def images_to_cifar(self, imgs):
         """CIFAR-10 records (uint8 array [n, 3073]) of a list of PIL images (or decoded pictures as
-        uint8 arrays [H, W, 3] / [H, W], which skips the PIL -> numpy copy), the resampling done on
+        uint8 arrays [H, W, 3] / [H, W, 4] / [H, W], which skips the PIL -> numpy copy), the resampling done on
         the GPU (``bnn_mi355x_images_to_cifar``): same bytes as :meth:`image_to_cifar` writes, but
         the caller's images are left as they are (the reference's ``thumbnail`` shrinks them in
-        place).  Modes other than RGB and L (alpha, palette, ...) take the PIL route on the host."""
+        place).  Modes other than RGB, RGBA and L (palette, LA, ...) take the PIL route on the host."""
         import io
         recs = np.empty((len(imgs), 3073), dtype=np.uint8)
         arrays, where = [], []
@@ -266,15 +266,15 @@ class CnvClassifier:
         on_device = hasattr(self.bnn.interface, "bnn_mi355x_images_to_cifar")
         for i, img in enumerate(imgs):
             if isinstance(img, np.ndarray):  # a decoded picture: uint8 [H, W, 3] (RGB) or [H, W] (L)
-                if img.dtype != np.uint8 or not (img.ndim == 2 or (img.ndim == 3 and img.shape[2] == 3)):
-                    raise ValueError("pictures given as arrays must be uint8 [H, W, 3] or [H, W]")
+                if img.dtype != np.uint8 or not (img.ndim == 2 or (img.ndim == 3 and img.shape[2] in (3, 4))):
+                    raise ValueError("pictures given as arrays must be uint8 [H, W, 3] (RGB), [H, W, 4] (RGBA) or [H, W] (L)")
                 if not on_device:
                     img = Image.fromarray(img)
                 else:
                     arrays.append(np.ascontiguousarray(img))
                     where.append(i)
                     continue
-            if on_device and img.mode in ("RGB", "L"):
+            if on_device and img.mode in ("RGB", "RGBA", "L"):
                 arrays.append(np.ascontiguousarray(np.asarray(img)))
                 where.append(i)
             else:

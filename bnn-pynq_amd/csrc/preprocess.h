@@ -8,7 +8,7 @@ namespace bnn {
 
 struct ResampleJob {
   const uint8_t *src;  // H x W x bands, rows `stride` bytes apart (device)
-  int w, h, bands;     // bands: 1 (L) or 3 (RGB)
+  int w, h, bands;     // bands: 1 (L), 3 (RGB) or 4 (RGBA: resampled with premultiplied alpha, like Pillow; modified in place)
   long stride;
   int out_w, out_h;    // 1..32 each; == w / h: that pass is skipped, like Pillow does
   const int32_t *kh, *bh;  // horizontal coefficients [out_w][ksize_h], bounds [out_w][2] (device)

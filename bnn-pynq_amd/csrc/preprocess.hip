@@ -44,6 +44,10 @@ __global__ __launch_bounds__(256) void k_resample_h(const uint8_t *__restrict__ 
   for (int b = 0; b < BANDS; b++) acc[b] = 0;
   if constexpr (BANDS == 1) {
     for (int j = lane; j < xmax; j += 64) acc[0] += (uint32_t)row[j] * (uint32_t)k[j];
+  } else if constexpr (BANDS == 4) {
+    // 64 = 0 mod 4: a lane stays on band (lane & 3); its sum goes to acc[0], the reduction below keeps bands apart
+    const int nbytes = xmax * 4;
+    for (int j = lane; j < nbytes; j += 64) acc[0] += (uint32_t)row[j] * (uint32_t)k[j >> 2];
   } else {
     // byte j of the window belongs to band j % 3; 192 = lcm(64, 3): a lane keeps its band
     // from one trip to the next only in steps of 192, so walk three interleaved strides
@@ -56,11 +60,34 @@ __global__ __launch_bounds__(256) void k_resample_h(const uint8_t *__restrict__ 
       if (b == 0) acc[0] += a; else if (b == 1) acc[1] += a; else acc[2] += a;
     }
   }
+  if constexpr (BANDS == 4) {
+    uint32_t v = acc[0];
 #pragma unroll
-  for (int b = 0; b < BANDS; b++) {
-    const uint32_t s = wave_sum(acc[b]) + (1u << (kPrec - 1));
-    if (lane == 0) dst[((size_t)y * out_w + xx) * BANDS + b] = clip8(s);
+    for (int off = 32; off >= 4; off >>= 1) v += __shfl_xor(v, off, 64);  // lanes 0..3 end up with bands 0..3
+    if (lane < 4) dst[((size_t)y * out_w + xx) * 4 + lane] = clip8(v + (1u << (kPrec - 1)));
+  } else {
+#pragma unroll
+    for (int b = 0; b < BANDS; b++) {
+      const uint32_t s = wave_sum(acc[b]) + (1u << (kPrec - 1));
+      if (lane == 0) dst[((size_t)y * out_w + xx) * BANDS + b] = clip8(s);
+    }
   }
+}
+
+// RGBA pictures are resampled with premultiplied alpha (Image.resize converts to "RGBa" and back): Pillow's
+// rgbA2rgba, c' = MULDIV255(c, a) = ((t = c * a + 128), ((t >> 8) + t) >> 8), alpha itself unchanged
+__global__ __launch_bounds__(256) void k_premultiply(uint8_t *__restrict__ px, size_t n_pixels) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_pixels) return;
+  uint32_t v = reinterpret_cast<uint32_t *>(px)[i];
+  const uint32_t a = v >> 24;
+  uint32_t out = v & 0xFF000000u;
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    const uint32_t t = ((v >> (8 * c)) & 0xFF) * a + 128;
+    out |= ((((t >> 8) + t) >> 8) & 0xFF) << (8 * c);
+  }
+  reinterpret_cast<uint32_t *>(px)[i] = out;
 }
 
 // Vertical pass + paste: one 1024-thread block per canvas row.  A canvas row holds `out_w x BANDS`
@@ -70,9 +97,9 @@ __global__ __launch_bounds__(256) void k_resample_h(const uint8_t *__restrict__ 
 template <int BANDS>
 __global__ __launch_bounds__(1024) void k_resample_v_paste(const uint8_t *__restrict__ src, long pitch, int out_w, int out_h,
                                                             const int32_t *__restrict__ kk, const int32_t *__restrict__ bounds, int ksize,
-                                                            int vertical, uint8_t *__restrict__ record) {
-  __shared__ uint32_t part[16][96];
-  __shared__ uint8_t line[96];
+                                                            int vertical, int premultiplied, uint8_t *__restrict__ record) {
+  __shared__ uint32_t part[16][128];
+  __shared__ uint8_t line[128];
   const int cy = blockIdx.x, t = threadIdx.x, wave = t >> 6, lane = t & 63;
   const int off_x = (32 - out_w) / 2, off_y = (32 - out_h) / 2;  // int((32 - size) / 2), size <= 32
   const int yy = cy - off_y;
@@ -103,7 +130,17 @@ __global__ __launch_bounds__(1024) void k_resample_v_paste(const uint8_t *__rest
   if (t < 96) {
     const int ch = t >> 5, cx = t & 31, xx = cx - off_x;
     uint8_t v = 255;  // the canvas: (255, 255, 255, 0), alpha is not part of the record
-    if (inside && xx >= 0 && xx < out_w) v = line[xx * BANDS + (BANDS == 3 ? ch : 0)];
+    if (inside && xx >= 0 && xx < out_w) {
+      v = line[xx * BANDS + (BANDS >= 3 ? ch : 0)];
+      if constexpr (BANDS == 4) {
+        // back from premultiplied alpha (Pillow's rgba2rgbA): copied when alpha is 0 or 255, else 255 c / a clipped
+        const uint32_t a = line[xx * 4 + 3];
+        if (premultiplied && a != 255 && a != 0) {
+          const uint32_t q = (255u * v) / a;
+          v = (uint8_t)(q > 255 ? 255 : q);
+        }
+      }
+    }
     record[1 + ch * 1024 + cy * 32 + cx] = v;
   }
 }
@@ -148,10 +185,15 @@ hipError_t launch_strip_records(const uint8_t *raw, int rec_bytes, int skip, uin
 hipError_t launch_image_to_cifar(const ResampleJob &j, hipStream_t s) {
   const bool horizontal = j.out_w != j.w;
   bool vertical = j.out_h != j.h;
+  const int premultiplied = (j.bands == 4 && (horizontal || vertical)) ? 1 : 0;
   const uint8_t *in = j.src;
   long pitch = j.stride;
   int rows = j.h;
   uint8_t *free_tmp = j.tmp;
+  if (premultiplied) {  // in place: j.src is the runtime's own copy of the picture, rows packed
+    const size_t n = (size_t)j.w * j.h;
+    hipLaunchKernelGGL(k_premultiply, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, const_cast<uint8_t *>(j.src), n);
+  }
   if (vertical && horizontal && j.vertical_first) {
     const int cols = j.w * j.bands;
     hipLaunchKernelGGL(k_resample_v, dim3((unsigned)((cols + 255) / 256), (unsigned)j.out_h), dim3(256), 0, s, in, pitch, cols, j.tmp,
@@ -168,14 +210,18 @@ hipError_t launch_image_to_cifar(const ResampleJob &j, hipStream_t s) {
     const int waves = rows * j.out_w;
     const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     if (j.bands == 3) hipLaunchKernelGGL(k_resample_h<3>, grid, block, 0, s, in, pitch, rows, free_tmp, j.out_w, j.kh, j.bh, j.ksize_h);
+    else if (j.bands == 4) hipLaunchKernelGGL(k_resample_h<4>, grid, block, 0, s, in, pitch, rows, free_tmp, j.out_w, j.kh, j.bh, j.ksize_h);
     else hipLaunchKernelGGL(k_resample_h<1>, grid, block, 0, s, in, pitch, rows, free_tmp, j.out_w, j.kh, j.bh, j.ksize_h);
     in = free_tmp;
     pitch = (long)j.out_w * j.bands;
   }
+  const int v = vertical ? 1 : 0;
   if (j.bands == 3)
-    hipLaunchKernelGGL(k_resample_v_paste<3>, dim3(32), dim3(1024), 0, s, in, pitch, j.out_w, j.out_h, j.kv, j.bv, j.ksize_v, vertical ? 1 : 0, j.record);
+    hipLaunchKernelGGL(k_resample_v_paste<3>, dim3(32), dim3(1024), 0, s, in, pitch, j.out_w, j.out_h, j.kv, j.bv, j.ksize_v, v, 0, j.record);
+  else if (j.bands == 4)
+    hipLaunchKernelGGL(k_resample_v_paste<4>, dim3(32), dim3(1024), 0, s, in, pitch, j.out_w, j.out_h, j.kv, j.bv, j.ksize_v, v, premultiplied, j.record);
   else
-    hipLaunchKernelGGL(k_resample_v_paste<1>, dim3(32), dim3(1024), 0, s, in, pitch, j.out_w, j.out_h, j.kv, j.bv, j.ksize_v, vertical ? 1 : 0, j.record);
+    hipLaunchKernelGGL(k_resample_v_paste<1>, dim3(32), dim3(1024), 0, s, in, pitch, j.out_w, j.out_h, j.kv, j.bv, j.ksize_v, v, 0, j.record);
   return hipGetLastError();
 }
 

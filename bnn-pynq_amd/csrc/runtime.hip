@@ -894,8 +894,8 @@ int bnn_mi355x_images_to_cifar(const uint8_t *const *pixels, const int *widths, 
   int ksize_h = 0, ksize_v = 0, ow = 0, oh = 0;
   for (int i = 0; i < n_images; i++) {
     const int w = widths[i], h = heights[i], nb = bands[i];
-    if (!pixels[i] || w < 1 || h < 1 || w > 65535 || h > 65535 || (nb != 1 && nb != 3))
-      return fail("images_to_cifar: image " + std::to_string(i) + ": need 1..65535 x 1..65535 pixels of 1 (L) or 3 (RGB) bytes");
+    if (!pixels[i] || w < 1 || h < 1 || w > 65535 || h > 65535 || (nb != 1 && nb != 3 && nb != 4))
+      return fail("images_to_cifar: image " + std::to_string(i) + ": need 1..65535 x 1..65535 pixels of 1 (L), 3 (RGB) or 4 (RGBA) bytes");
     const size_t row_bytes = (size_t)w * nb;
     const long stride = row_strides ? row_strides[i] : (long)row_bytes;
     if (stride < (long)row_bytes) return fail("images_to_cifar: row stride shorter than a row");
@@ -915,7 +915,7 @@ int bnn_mi355x_images_to_cifar(const uint8_t *const *pixels, const int *widths, 
       HIP_OK(hipMemcpyAsync(r.d_pp_coef, keep.back().data(), keep.back().size() * sizeof(int32_t), hipMemcpyHostToDevice, r.stream));
       last_w = w; last_h = h;
     }
-    if (grow(r.d_pp_src, r.pp_src_cap, row_bytes * h) || grow(r.d_pp_tmp, r.pp_tmp_cap, (size_t)(h > w ? h : w) * 32 * 3 + 3072)) return -1;
+    if (grow(r.d_pp_src, r.pp_src_cap, row_bytes * h) || grow(r.d_pp_tmp, r.pp_tmp_cap, (size_t)(h > w ? h : w) * 32 * 4 + 4096)) return -1;
     if ((size_t)stride == row_bytes)
       HIP_OK(hipMemcpyAsync(r.d_pp_src, pixels[i], row_bytes * h, hipMemcpyHostToDevice, r.stream));
     else

@@ -138,10 +138,11 @@ size_t bnn_mi355x_pack_params_faulty(const char *path, const int *records, int n
  * a CIFAR-10 record: label byte 1, then the R, G, B planes (3073 bytes).  These two entry points do the
  * same for decoded pictures in host memory; the records are bit-identical to Pillow's
  * (tests/test_image_to_cifar.py).  CNV libraries only.
- *   pixels[i]: heights[i] rows of widths[i] pixels of bands[i] bytes (1 = mode "L", 3 = mode "RGB"),
+ *   pixels[i]: heights[i] rows of widths[i] pixels of bands[i] bytes (1 = mode "L", 3 = "RGB", 4 = "RGBA":
+ *              resampled with premultiplied alpha like Image.resize does, the alpha channel then dropped),
  *              rows row_strides[i] bytes apart (row_strides NULL: packed rows);
  *   records:   n_images x 3073 bytes, host.
- * Pictures of other modes (alpha, palette) stay with PIL on the host, like in the reference.
+ * Pictures of other modes (palette, LA, CMYK, ...) stay with PIL on the host, like in the reference.
  * thumbnail_size: the size Image.thumbnail((32, 32)) gives a width x height picture; returns 1 when
  * the picture is resampled, 0 when it already fits (out = in). */
 int bnn_mi355x_thumbnail_size(int width, int height, int *out_w, int *out_h);

@@ -32,7 +32,7 @@ def pil_record(img):
 
 def picture(w, h, mode, seed, kind):
     rng = np.random.default_rng(seed)
-    shape = (h, w, 3) if mode == "RGB" else (h, w)
+    shape = (h, w) if mode == "L" else (h, w, 3)
     if kind == "noise":
         a = rng.integers(0, 256, shape, dtype=np.uint8)
     elif kind == "blocks":  # saturated blocks: the Lanczos lobes overshoot, clip8 works at both ends
@@ -44,8 +44,13 @@ def picture(w, h, mode, seed, kind):
         yy, xx = np.mgrid[0:h, 0:w]
         g = (yy * 255.0 / max(h - 1, 1) * 0.5 + xx * 255.0 / max(w - 1, 1) * 0.5)
         a = np.clip(g + rng.normal(0, 3, (h, w)), 0, 255).astype(np.uint8)
-        if mode == "RGB":
+        if mode != "L":
             a = np.stack([a, a[::-1], a[:, ::-1]], axis=2)
+    if mode == "RGBA":  # colour planes as for RGB, alpha: every regime of the premultiply / unpremultiply pair
+        alpha = rng.choice(np.array([0, 1, 2, 17, 128, 200, 254, 255], np.uint8), size=(h, w), p=[.15, .05, .05, .1, .15, .15, .1, .25])
+        if kind == "smooth":
+            alpha = np.clip(np.mgrid[0:h, 0:w][1] * 255.0 / max(w - 1, 1) + rng.normal(0, 2, (h, w)), 0, 255).astype(np.uint8)
+        a = np.dstack([a, alpha])
     return Image.fromarray(np.ascontiguousarray(a), mode)
 
 
@@ -77,7 +82,7 @@ def clf():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["RGB", "L"])
+@pytest.mark.parametrize("mode", ["RGB", "L", "RGBA"])
 @pytest.mark.parametrize("kind", ["noise", "blocks", "smooth"])
 def test_records_equal_pillow(clf, mode, kind):
     imgs = [picture(w, h, mode, 11 * i + len(kind), kind) for i, (w, h) in enumerate(SIZES)]
@@ -92,12 +97,12 @@ def test_records_equal_pillow(clf, mode, kind):
 @pytest.mark.gpu
 def test_mixed_batch_modes_and_repeated_sizes(clf):
     """one call, pictures of changing and repeating sizes (coefficient tables are reused while the size
-    repeats), RGBA and palette pictures taking the host route in between"""
+    repeats), LA and palette pictures taking the host route in between"""
     imgs = []
     for i in range(24):
         w, h = [(200, 100), (200, 100), (64, 48), (200, 100)][i % 4]
         imgs.append(picture(w, h, "RGB" if i % 3 else "L", 100 + i, "noise"))
-    imgs.insert(5, picture(80, 60, "RGB", 1, "smooth").convert("RGBA"))
+    imgs.insert(5, picture(80, 60, "RGB", 1, "smooth").convert("LA"))
     imgs.insert(9, picture(90, 50, "RGB", 2, "blocks").convert("P"))
     recs = clf.images_to_cifar(imgs)
     for im, r in zip(imgs, recs):
@@ -106,7 +111,7 @@ def test_mixed_batch_modes_and_repeated_sizes(clf):
     as_arrays = [np.asarray(im) for im in imgs[:5]]
     assert (clf.images_to_cifar(as_arrays) == recs[:5]).all()
     with pytest.raises(ValueError):
-        clf.images_to_cifar([np.zeros((4, 4, 4), np.uint8)])
+        clf.images_to_cifar([np.zeros((4, 4, 2), np.uint8)])
 
 
 @pytest.mark.gpu
@@ -119,7 +124,7 @@ def test_row_stride_and_errors(clf):
     out = np.zeros((1, 3073), np.uint8)
     assert L.bnn_mi355x_images_to_cifar(ptrs, one(300), one(200), one(3), (C.c_long * 1)(1500), 1, out.ctypes.data) == 0
     assert (out[0] == pil_record(Image.fromarray(np.ascontiguousarray(view), "RGB"))).all()
-    assert L.bnn_mi355x_images_to_cifar(ptrs, one(300), one(200), one(4), None, 1, out.ctypes.data) == -1
+    assert L.bnn_mi355x_images_to_cifar(ptrs, one(300), one(200), one(2), None, 1, out.ctypes.data) == -1
     assert b"bytes" in L.bnn_mi355x_last_error()
     assert L.bnn_mi355x_images_to_cifar(ptrs, one(300), one(200), one(3), (C.c_long * 1)(100), 1, out.ctypes.data) == -1
     assert L.bnn_mi355x_images_to_cifar(None, None, None, None, None, 0, None) == 0
