@@ -260,38 +260,46 @@ class CnvClassifier:
         the caller's images are left as they are (the reference's ``thumbnail`` shrinks them in
         place).  Modes other than RGB, RGBA and L (palette, LA, ...) take the PIL route on the host."""
         import io
+        from concurrent.futures import ThreadPoolExecutor
         recs = np.empty((len(imgs), 3073), dtype=np.uint8)
-        arrays, where = [], []
         # a library with only the reference's six symbols (the reference's own .so) has no such entry point
         on_device = hasattr(self.bnn.interface, "bnn_mi355x_images_to_cifar")
-        for i, img in enumerate(imgs):
-            if isinstance(img, np.ndarray):  # a decoded picture: uint8 [H, W, 3] (RGB) or [H, W] (L)
+
+        def decoded(img):
+            """uint8 array for the device route, None for the PIL route"""
+            if isinstance(img, np.ndarray):  # a decoded picture
                 if img.dtype != np.uint8 or not (img.ndim == 2 or (img.ndim == 3 and img.shape[2] in (3, 4))):
                     raise ValueError("pictures given as arrays must be uint8 [H, W, 3] (RGB), [H, W, 4] (RGBA) or [H, W] (L)")
-                if not on_device:
-                    img = Image.fromarray(img)
-                else:
-                    arrays.append(np.ascontiguousarray(img))
-                    where.append(i)
-                    continue
+                return np.ascontiguousarray(img) if on_device else None
             if on_device and img.mode in ("RGB", "RGBA", "L"):
-                arrays.append(np.ascontiguousarray(np.asarray(img)))
-                where.append(i)
-            else:
-                buf = io.BytesIO()
-                self.image_to_cifar(img.copy(), buf)
-                recs[i] = np.frombuffer(buf.getvalue(), dtype=np.uint8)
-        n = len(arrays)
-        if n:
-            ptrs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrays])
-            ws = (ctypes.c_int * n)(*[a.shape[1] for a in arrays])
-            hs = (ctypes.c_int * n)(*[a.shape[0] for a in arrays])
-            bs = (ctypes.c_int * n)(*[1 if a.ndim == 2 else a.shape[2] for a in arrays])
-            out = np.empty((n, 3073), dtype=np.uint8)
-            lib = self.bnn.interface
-            if lib.bnn_mi355x_images_to_cifar(ptrs, ws, hs, bs, None, n, out.ctypes.data) != 0:
-                raise RuntimeError(lib.bnn_mi355x_last_error().decode())
-            recs[where] = out
+                return np.ascontiguousarray(np.asarray(img))  # (decodes lazily opened files: PIL releases the GIL there)
+            return None
+
+        # a bounded number of decoded pictures in memory at a time; decoding on a few threads
+        CHUNK = 32
+        with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+            for base in range(0, len(imgs), CHUNK):
+                part = imgs[base:base + CHUNK]
+                arrays = list(pool.map(decoded, part)) if len(part) > 1 else [decoded(part[0])]
+                dev = [(base + i, a) for i, a in enumerate(arrays) if a is not None]
+                for i, a in enumerate(arrays):
+                    if a is None:  # the reference's own procedure, on the host
+                        img = part[i]
+                        buf = io.BytesIO()
+                        self.image_to_cifar(Image.fromarray(img) if isinstance(img, np.ndarray) else img.copy(), buf)
+                        recs[base + i] = np.frombuffer(buf.getvalue(), dtype=np.uint8)
+                n = len(dev)
+                if n:
+                    arrs = [a for _, a in dev]
+                    ptrs = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrs])
+                    ws = (ctypes.c_int * n)(*[a.shape[1] for a in arrs])
+                    hs = (ctypes.c_int * n)(*[a.shape[0] for a in arrs])
+                    bs = (ctypes.c_int * n)(*[1 if a.ndim == 2 else a.shape[2] for a in arrs])
+                    out = np.empty((n, 3073), dtype=np.uint8)
+                    lib = self.bnn.interface
+                    if lib.bnn_mi355x_images_to_cifar(ptrs, ws, hs, bs, None, n, out.ctypes.data) != 0:
+                        raise RuntimeError(lib.bnn_mi355x_last_error().decode())
+                    recs[[i for i, _ in dev]] = out
         return recs
 
     def _with_tmp(self, imgs, fn):
