@@ -24,8 +24,12 @@
 //     stored once: outputs are already in the bit-packed layout the next stage
 //     reads.  Max-pool is a min/max over the quad's 4 accumulators before the
 //     threshold compare (thresholding is monotone), so it is free.
-//   * No MFMA: the path is bitwise.  No LDS: there is no data shared between
-//     lanes that the scalar path does not already broadcast for free.
+//   * No MFMA in the bitwise layers.  No LDS in the throughput kernels: there is no data shared
+//     between lanes that the scalar path does not already broadcast for free.  The exceptions,
+//     each argued where it is defined: the int8 first layer runs on the matrix pipe
+//     (k_conv0_mfma); small batches, where a lane per item leaves the chip empty, use a lane
+//     per output pixel, 8-neuron blocks, a wave per image (k_fclast_wave) and the one-launch
+//     block-per-image kernels with LDS + wave ballots (k_lfc_fused*, k_cnv_tail*).
 //
 // Data layout in HBM: see DESIGN.md ("Data layout").
 #include <hip/hip_runtime.h>
