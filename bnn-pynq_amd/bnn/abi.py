@@ -17,7 +17,8 @@ EXT = ["bnn_mi355x_network", "bnn_mi355x_image_bytes", "bnn_mi355x_last_error", 
        "bnn_mi355x_inference_buffer", "bnn_mi355x_inference_raw", "bnn_mi355x_inference_device",
        "bnn_mi355x_reserve", "bnn_mi355x_set_fault_seed", "bnn_mi355x_last_faults", "bnn_mi355x_plan_faults",
        "bnn_mi355x_pack_params_faulty", "bnn_mi355x_debug_stage_output", "bnn_mi355x_profile",
-       "bnn_mi355x_profile_read", "bnn_mi355x_stage_name", "bnn_mi355x_thumbnail_size", "bnn_mi355x_images_to_cifar"]
+       "bnn_mi355x_profile_read", "bnn_mi355x_stage_name", "bnn_mi355x_thumbnail_size", "bnn_mi355x_images_to_cifar",
+       "bnn_mi355x_params_bytes", "bnn_mi355x_import_params_device", "bnn_mi355x_params_crc"]
 
 
 def lib_path(network, runtime="python_sw", lib_dir=None):
@@ -52,6 +53,11 @@ def declare_extensions(L):
     L.bnn_mi355x_export_params.argtypes = [C.c_void_p, C.c_size_t]
     L.bnn_mi355x_export_params.restype = C.c_size_t
     L.bnn_mi355x_import_params.argtypes = [C.c_void_p, C.c_size_t]
+    L.bnn_mi355x_params_bytes.argtypes = []
+    L.bnn_mi355x_params_bytes.restype = C.c_size_t
+    L.bnn_mi355x_import_params_device.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+    L.bnn_mi355x_params_crc.argtypes = []
+    L.bnn_mi355x_params_crc.restype = C.c_uint
     L.bnn_mi355x_inference_buffer.argtypes = [C.c_void_p, C.c_int, C.c_int, fp, C.c_int]
     L.bnn_mi355x_inference_buffer.restype = ip
     L.bnn_mi355x_inference_raw.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, fp]

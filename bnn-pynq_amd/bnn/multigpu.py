@@ -35,35 +35,45 @@ def pack_params(lib, param_dir):
     return blob
 
 
-def broadcast_blob(blob, src=0, device=None, group=None):
-    """rank `src` passes the blob, the others None; everyone returns the same numpy uint8 array.
-    Two broadcasts (size, bytes) over whatever backend the group uses."""
+def broadcast_blob(lib, blob, src=0, device=None, group=None):
+    """ONE collective: rank `src` passes the packed blob (numpy uint8), the others None; every rank returns
+    the received bytes as a uint8 torch tensor on `device` (CPU when None).  The size needs no exchange: it
+    is a function of the network alone (``bnn_mi355x_params_bytes``)."""
     import torch
     import torch.distributed as dist
     rank = dist.get_rank(group)
     dev = device if device is not None else torch.device("cpu")
-    size = torch.tensor([blob.size if rank == src else 0], dtype=torch.int64, device=dev)
-    dist.broadcast(size, src, group=group)
+    size = int(lib.bnn_mi355x_params_bytes())
     if rank == src:
+        if blob.size != size:
+            raise RuntimeError("packed blob has %d bytes, this network's layout has %d" % (blob.size, size))
         buf = torch.from_numpy(np.ascontiguousarray(blob)).to(dev)
     else:
-        buf = torch.empty(int(size.item()), dtype=torch.uint8, device=dev)
+        buf = torch.empty(size, dtype=torch.uint8, device=dev)
     dist.broadcast(buf, src, group=group)
-    return buf.cpu().numpy()
+    return buf
 
 
 def distribute_params(lib, param_dir, device=None, group=None, upload=True):
-    """load_parameters() for a multi-GPU job: rank 0 reads and repacks the reference's param files,
-    every rank receives the blob over the process group and (upload=True) hands it to its own
-    library instance / GPU.  Returns the blob."""
+    """load_parameters() for a multi-GPU job: rank 0 reads and repacks the reference's param files, every
+    rank receives the blob in one broadcast over the process group and (upload=True) hands it to its own
+    library instance -- straight from HBM when the group's tensors live there (RCCL), from host memory
+    otherwise (gloo).  Returns the blob as a numpy array (host copy; the GPU path makes it on demand)."""
+    import torch
     import torch.distributed as dist
     rank = dist.get_rank(group)
     blob = pack_params(lib, param_dir) if rank == 0 else None
-    blob = broadcast_blob(blob, 0, device, group)
+    buf = broadcast_blob(lib, blob, 0, device, group)
     if upload:
-        if lib.bnn_mi355x_import_params(blob.ctypes.data, blob.size) != 0:
+        if buf.is_cuda:
+            stream = torch.cuda.current_stream(buf.device).cuda_stream
+            rc = lib.bnn_mi355x_import_params_device(buf.data_ptr(), buf.numel(), stream)
+        else:
+            host = buf.numpy()
+            rc = lib.bnn_mi355x_import_params(host.ctypes.data, host.size)
+        if rc != 0:
             raise RuntimeError(lib.bnn_mi355x_last_error().decode())
-    return blob
+    return buf.cpu().numpy()
 
 
 def gather_classes(local_classes, n_total, group=None):

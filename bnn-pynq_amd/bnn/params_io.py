@@ -97,3 +97,172 @@ def read_params(directory, network):
         weights.append(W)
         thresholds.append(T)
     return weights, thresholds
+
+
+# ======================================================================================================
+# Float model -> integer matrices: the other half of finnthesizer.py (makeFCBNComplex, makeFCBNComplex_QNN,
+# makeConvBNComplex, finnthesizer.py:169-330; BNNWeightReader's FC column interleave :374-387; the padding
+# and saturation of BNNProcElemMem :528-555,616-690; the per-network drivers cifar10-gen-weights-*.py,
+# mnist-gen-weights-*.py / convertFCNetwork :40-100), restated for Python 3 on whole arrays.
+#
+# "parity unpinned": the trained .npz archives these functions were written for are missing blobs in the
+# reference checkout and the tool itself is Python 2, so no byte comparison with shipped parameter files
+# is possible.  What is tested instead (tests/test_synthesize.py): a random float network evaluated in
+# floating point, layer by layer, makes the same decisions as the oracle / the GPU runtime on the derived
+# parameter files, and the hand-checkable properties of each formula.
+#
+# A layer of the float model is a dict of numpy arrays, in the order the training scripts store them
+# (finnthesizer.py BNNWeightReader: W, then bias, beta, gamma, mean, invstd):
+#   W        FC: [ins, outs] (a Lasagne DenseLayer: neurons in COLUMNS); conv: [out_ch, in_ch, k, k]
+#   bias, beta, gamma, mean, invstd   [outs]: layer bias and batch-norm parameters,
+#            y = (W.x + bias - mean) * invstd * gamma + beta ; activation = quantiser of y
+# ======================================================================================================
+def _quantize_weights(w, wbits):
+    """finnthesizer.py quantize()/binarize(): 1 bit: +1 where w >= 0 else -1 (the file bit is 1 / 0);
+    more bits: floor(w + 0.5) (round half up, no clipping: training keeps the weights inside [-1, 1])"""
+    if wbits == 1:
+        return np.where(w >= 0, 1, -1).astype(np.int64)
+    return np.floor(w + 0.5).astype(np.int64)
+
+
+def _steps(abits):
+    """decision levels of the activation quantiser on the batch-norm output: none but 0 for 1 bit; for A2
+    {-0.5, +0.5} (np.linspace(-1, 1, 2^(A-1), endpoint=False) + 1/2, finnthesizer.py:223,270)"""
+    if abits == 1:
+        return np.zeros(1)
+    return np.linspace(-1, 1, num=2 ** (abits - 1), endpoint=False) + 0.5
+
+
+def bn_thresholds(fanin, bias, beta, gamma, mean, invstd, abits=1, use_popcount=True, frac_bits=0, conv=True):
+    """Batch-norm + quantiser of one layer as integer thresholds on the accumulator.
+    Returns (T [outs, nthr] float64 holding integers, flip [outs] bool); rows with flip have gamma*invstd < 0:
+    their weights must be negated so that every neuron fires on the positive side.
+
+    1-bit activations: t = mean - bias - beta / (gamma * invstd) on the signed sum; conv layers round it
+    floor(f*t) / ceil(-f*t) with f = 2^frac_bits (finnthesizer.py:285-293), FC layers do not (:183-193);
+    with use_popcount the compare moves to the number of matches: int((fanin + t) / 2), int() truncating
+    toward zero as in Python 2.  2-bit activations: one threshold per level,
+    t_i = mean - bias + (step_i - beta) / (gamma * invstd), floor(f*t) / ceil(-f*t) (:230-240,:300-306).
+    """
+    bias, beta, gamma, mean, invstd = (np.asarray(a, np.float64) for a in (bias, beta, gamma, mean, invstd))
+    scale = gamma * invstd
+    flip = scale < 0
+    f = float(2 ** frac_bits)
+    if abits == 1:
+        t = (mean - bias) - beta / scale
+        if conv:
+            t = np.where(flip, np.ceil(-f * t), np.floor(f * t))
+        else:
+            t = np.where(flip, -t, t)
+        if use_popcount:
+            t = np.trunc((fanin + t) / 2.0)
+        elif not conv:
+            t = np.trunc(t)
+        return t[:, None], flip
+    step = _steps(abits)
+    t = (mean - bias)[:, None] + (step[None, :] - beta[:, None]) / scale[:, None]
+    t = np.where(flip[:, None], np.ceil(-f * t), np.floor(f * t))
+    return t, flip
+
+
+def fc_layer(layer, wbits=1, abits=1, ibits=1):
+    """makeFCBNComplex / makeFCBNComplex_QNN as called by readFCBNComplex (finnthesizer.py:361-372): the
+    popcount form only when weights, activations AND inputs are 1-bit.  layer["W"] is [ins, outs].
+    A layer without batch-norm entries (CNV layer 8, readFCBNComplex_no_thresholds :395-412) gets the
+    reference's stand-in parameters.  Returns (Wq [outs, ins], T [outs, nthr])."""
+    W = np.asarray(layer["W"], np.float64)
+    ins, outs = W.shape
+    if "gamma" in layer:
+        bn = [layer[k] for k in ("bias", "beta", "gamma", "mean", "invstd")]
+    else:
+        bn = [np.zeros(outs), np.zeros(outs), np.ones(outs), np.ones(outs), np.ones(outs)]
+    T, flip = bn_thresholds(ins, *bn, abits=abits, use_popcount=(wbits == 1 and abits == 1 and ibits == 1), conv=False)
+    Wq = _quantize_weights(np.where(flip[None, :], -W, W), wbits).T
+    return Wq, T
+
+
+def conv_layer(layer, wbits=1, abits=1, use_popcount=True, frac_bits=0, interleave_channels=True):
+    """makeConvBNComplex (finnthesizer.py:258-330).  layer["W"] is [out_ch, in_ch, k, k]; the matrix column
+    order is (ky, kx, in_ch) with interleave_channels (what every shipped network uses), else (in_ch, ky, kx).
+    Returns (Wq [out_ch, in_ch*k*k], T [out_ch, nthr])."""
+    W = np.asarray(layer["W"], np.float64)
+    out_ch, in_ch, k, k2 = W.shape
+    if k != k2:
+        raise ValueError("Nonsymmetric conv kernels are not yet supported")
+    T, flip = bn_thresholds(in_ch * k * k, *[layer[n] for n in ("bias", "beta", "gamma", "mean", "invstd")], abits=abits,
+                            use_popcount=use_popcount and abits == 1, frac_bits=frac_bits, conv=True)
+    Wf = np.where(flip[:, None, None, None], -W, W)
+    if interleave_channels:
+        Wf = Wf.transpose(0, 2, 3, 1)
+    return _quantize_weights(Wf.reshape(out_ch, in_ch * k * k), wbits), T
+
+
+def interleave_fc_columns(Wq, channels):
+    """first FC layer behind a conv stack: the conv output reaches it pixel-major / channel-minor, the trained
+    matrix has its columns channel-major (finnthesizer.py:374-387): column chan*P + pix -> pix*C + chan"""
+    outs, ins = Wq.shape
+    pix = ins // channels
+    return Wq.reshape(outs, channels, pix).transpose(0, 2, 1).reshape(outs, ins)
+
+
+def pad_layer(Wq, T, mh, mw, wbits, abits, ibits, thres_bits=16):
+    """BNNProcElemMem.__padMatrix + the saturation of __tmem2bin (finnthesizer.py:528-555,660-674): pad the
+    matrix to [mh, mw] -- padding weights +1 (1-bit; the padding INPUT bits are 0) resp. 0 (2-bit) --, padding
+    neurons get the largest threshold; where a padding column is not transparent (+-1 arithmetic on a padded
+    input: not the all-1-bit popcount form and not 2-bit weights) its contribution of -1 per column is taken
+    off the thresholds (AccuOffset); thresholds saturate to thres_bits-bit integers."""
+    n, s = Wq.shape
+    W = np.full((mh, mw), 1 if wbits == 1 else 0, np.int64)
+    W[:n, :s] = Wq
+    Tp = np.full((mh, T.shape[1]), float(2 ** thres_bits - 1))
+    Tp[:n] = T
+    transparent = (wbits == 1 and abits == 1 and ibits == 1) or wbits >= 2
+    if not transparent:
+        Tp = Tp - (mw - s)
+    lo, hi = -(2 ** (thres_bits - 1)), 2 ** (thres_bits - 1) - 1
+    return W, np.trunc(np.clip(Tp, lo, hi)).astype(np.int64)
+
+
+def synthesize(network, layers):
+    """A trained float network -> the integer matrices write_params() takes, for one of the five shipped
+    topologies, following the per-network drivers (cifar10-gen-weights-W1A1.py:75-178 and its W1A2 / W2A2
+    siblings; mnist-gen-weights-*.py + convertFCNetwork).  `layers`: one dict per layer (see above).
+    CNV layer 0 takes 8-bit fixed-point inputs: thresholds in units of 2^-8 (numThresBits=24,
+    numThresIntBits=16), then saturated to 16 bits like every other layer, because the memory object is
+    built with its defaults (cifar10-gen-weights-W1A1.py:88,99).  Returns (weights, thresholds)."""
+    lay = layout(network)
+    cnv = network.startswith("cnv")
+    wbits = 2 if "W2" in network else 1
+    a2 = network.endswith("A2")
+    nl = len(lay)
+    weights, thresholds = [], []
+    for l, (L, P) in enumerate(zip(lay, layers)):
+        abits = 1 if (l == nl - 1 or not a2) else 2        # ActivationPrecisions_integer: last layer 1
+        ibits = (8 if cnv else 1) if l == 0 else (2 if a2 else 1)
+        if cnv and l < 6:
+            Wq, T = conv_layer(P, wbits, abits, use_popcount=(l > 0 and not a2 and wbits == 1), frac_bits=8 if l == 0 else 0)
+        else:
+            Wq, T = fc_layer(P, wbits, abits, ibits)
+            if cnv and l == 6:
+                Wq = interleave_fc_columns(Wq, 256)          # conv layer 5 has 256 channels of one pixel: the identity
+        W, Tp = pad_layer(Wq, T, L["mh"], L["mw"], wbits, abits, ibits)
+        weights.append(W)
+        thresholds.append(Tp if L["nthr"] else np.zeros((L["mh"], 1), np.int64))
+    return weights, thresholds
+
+
+def read_npz_layers(path, network):
+    """the training scripts' archive (arr_0, arr_1, ...: W, bias, beta, gamma, mean, invstd per layer; the last
+    CNV layer has no batch norm) -> the list of layer dicts synthesize() takes"""
+    z = np.load(path, allow_pickle=False)
+    nl = len(layout(network))
+    out, i = [], 0
+    for l in range(nl):
+        d = {"W": z["arr_%d" % i]}
+        i += 1
+        if not (network.startswith("cnv") and l == nl - 1):
+            for k in ("bias", "beta", "gamma", "mean", "invstd"):
+                d[k] = z["arr_%d" % i]
+                i += 1
+        out.append(d)
+    return out

@@ -14,16 +14,20 @@ uint32_t thresh_bits(const LayerSpec &L) { return (uint32_t)L.fold.tmem * L.fold
 
 }  // namespace
 
-std::vector<Fault> plan_faults(const NetSpec &net, uint64_t seed, int num_images, unsigned flip_count, int word_size,
-                               int target_type, const int *target_layers, unsigned num_layers) {
-  std::vector<Fault> out;
-  if (num_images <= 0 || flip_count == 0) return out;
+std::string plan_faults(const NetSpec &net, uint64_t seed, int num_images, unsigned flip_count, int word_size,
+                        int target_type, const int *target_layers, unsigned num_layers, std::vector<Fault> &out) {
+  out.clear();
+  if (num_images <= 0 || flip_count == 0) return "";
   std::mt19937_64 gen(seed ? seed : (uint64_t)std::random_device{}());
   // candidate layers: the caller's list, or every layer (the reference leaves the empty list to
   // std::discrete_distribution over two zero weights; "all layers" is the evident intent)
   std::vector<int> layers;
-  for (unsigned i = 0; i < num_layers; i++)
-    if (target_layers && target_layers[i] >= 0 && target_layers[i] < net.nlayers) layers.push_back(target_layers[i]);
+  for (unsigned i = 0; target_layers && i < num_layers; i++) {
+    // (the reference indexes its topology tables with whatever it is given; a campaign that silently ran on
+    // other layers than the ones asked for would be mislabelled, so this is an error here)
+    if (target_layers[i] < 0 || target_layers[i] >= net.nlayers) return "fault injection: target layer out of range";
+    layers.push_back(target_layers[i]);
+  }
   if (layers.empty())
     for (int l = 0; l < net.nlayers; l++) layers.push_back(l);
   std::vector<double> wb, tb;
@@ -32,6 +36,7 @@ std::vector<Fault> plan_faults(const NetSpec &net, uint64_t seed, int num_images
     wb.push_back(weight_bits(net.L[l])); wsum += wb.back();
     tb.push_back(thresh_bits(net.L[l])); tsum += tb.back();
   }
+  if (target_type > 0 && tsum == 0) return "fault injection: no threshold memory in the targeted layers";
   // fault times: uniform over the image indices (faults.h:124-131)
   std::uniform_int_distribution<int> when(0, num_images - 1);
   std::vector<int> times(flip_count);
@@ -44,7 +49,6 @@ std::vector<Fault> plan_faults(const NetSpec &net, uint64_t seed, int num_images
     bool weights;
     if (target_type < 0) weights = std::discrete_distribution<int>({wsum, tsum})(gen) == 0;
     else weights = (target_type == 0);
-    if (!weights && tsum == 0) weights = true;
     const std::vector<double> &space = weights ? wb : tb;
     std::discrete_distribution<int> pick(space.begin(), space.end());
     const int l = layers[pick(gen)];
@@ -70,7 +74,7 @@ std::vector<Fault> plan_faults(const NetSpec &net, uint64_t seed, int num_images
     }
     out.push_back(f);
   }
-  return out;
+  return "";
 }
 
 int apply_fault(const NetSpec &net, RawParams &raw, const Fault &f) {

@@ -9,6 +9,7 @@
 // (bnn_mi355x_set_fault_seed) so that a campaign can be replayed and checked.
 #pragma once
 #include <cstdint>
+#include <string>
 #include <vector>
 
 #include "packed_params.h"
@@ -22,9 +23,11 @@ struct Fault {
   int layer, mem, ind, thresh, bit, word_size;
 };
 
-// target_type: < 0 any, 0 weights, > 0 thresholds (main_python.cpp:105-108)
-std::vector<Fault> plan_faults(const NetSpec &net, uint64_t seed, int num_images, unsigned flip_count, int word_size,
-                               int target_type, const int *target_layers, unsigned num_layers);
+// target_type: < 0 any, 0 weights, > 0 thresholds (main_python.cpp:105-108).  Returns "" and the plan, or the
+// reason why the request cannot be honoured as asked (a target layer outside the network; thresholds-only
+// faults on layers without threshold memory): never a silently different campaign.
+std::string plan_faults(const NetSpec &net, uint64_t seed, int num_images, unsigned flip_count, int word_size,
+                        int target_type, const int *target_layers, unsigned num_layers, std::vector<Fault> &out);
 
 // inject_fault_impl on the raw memories; returns the matrix row whose packed form changed, or -1
 int apply_fault(const NetSpec &net, RawParams &raw, const Fault &f);

@@ -35,6 +35,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "kernels.h"

@@ -158,7 +158,11 @@ void fill_l0_mfma(const NetSpec &net, const RawParams &raw, uint8_t *dst) {
           for (int kx = 0; kx < 3; kx++) a[n * 32 + 3 * (c * 3 + ky) + kx] = (int8_t)F.weight(n, (ky * 3 + kx) * 3 + c);
       const int32_t T = F.threshold(n, (which && L.nthr > 1) ? 1 : 0);
       const int32_t t = floor_div2(T);
-      const int32_t tc = t > 3456 ? 3456 : (t < -3457 ? -3457 : t);  // |dot| <= 27*128: same decisions
+      // clamp to the reachable range of the dot product (same decisions): |dot| <= 27*128 for weights in
+      // {-1,0,+1}; ap_int<2> weights can be -2 after a bit flip (cnvW2A2), which doubles the range.  With
+      // |v| <= 6914, a1 = floor((v + 32) / 64) still fits int8.
+      const int32_t lim = (L.wbits == 2) ? 2 * 3456 : 3456;
+      const int32_t tc = t > lim ? lim : (t < -lim - 1 ? -lim - 1 : t);
       const int32_t v = -tc - 1;
       const int32_t a1 = (v + 32 + 64 * 128) / 64 - 128;  // floor((v + 32) / 64)
       a[n * 32 + 27] = (int8_t)(v - 64 * a1);
@@ -252,18 +256,29 @@ std::string pack_params_from_dir(const NetSpec &net, const std::string &dir, std
   return "";
 }
 
+size_t blob_bytes(const NetSpec &net) {
+  PackedHeader h;
+  layout_header(net, h);
+  return h.total_bytes;
+}
+
 std::string validate_blob(const NetSpec &net, const void *blob, size_t bytes) {
   if (bytes < sizeof(PackedHeader)) return "packed params: blob shorter than its header";
-  PackedHeader h;
+  PackedHeader h, want;
   std::memcpy(&h, blob, sizeof(h));
   if (h.magic0 != kBlobMagic0 || h.magic1 != kBlobMagic1) return "packed params: bad magic";
   if (h.version != kBlobVersion) return "packed params: version mismatch";
   if (h.net_id != (uint32_t)net.id) return std::string("packed params: blob is not for network ") + net.name;
-  if (h.nlayers != (uint32_t)net.nlayers || h.total_bytes != bytes) return "packed params: size mismatch";
-  for (int l = 0; l < net.nlayers; l++) {
-    const PackedLayer &p = h.layer[l];
-    if (p.row_dwords != row_dwords_for(net.L[l]) || p.rows != (uint32_t)net.L[l].mh()) return "packed params: layer shape mismatch";
-    if ((size_t)p.offset + (size_t)p.row_dwords * 4 * p.rows > bytes) return "packed params: layer out of bounds";
+  // The layout is a function of the network alone: the bytes come from outside (broadcast, file), and every
+  // field of the header is later used as an offset or a stride on the host and on the device -- so each one
+  // must be exactly what this library would have written, not merely plausible.
+  layout_header(net, want);
+  if (h.nlayers != want.nlayers || h.total_bytes != want.total_bytes || bytes != want.total_bytes) return "packed params: size mismatch";
+  if (h.l0_mfma_offset != want.l0_mfma_offset || h.reserved1 != 0) return "packed params: layer-0 table offset mismatch";
+  for (int l = 0; l < 9; l++) {
+    const PackedLayer &p = h.layer[l], &q = want.layer[l];
+    if (p.row_dwords != q.row_dwords || p.rows != q.rows || p.kw != q.kw) return "packed params: layer shape mismatch";
+    if (p.offset != q.offset) return "packed params: layer offset mismatch";
   }
   return "";
 }

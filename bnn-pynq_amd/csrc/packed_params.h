@@ -96,6 +96,10 @@ std::string pack_params_from_dir(const NetSpec &net, const std::string &dir, std
 // Number of rows (2-bit-weight layers only) holding a weight of -2, i.e. with their flag dword set.
 int count_two_rows(const NetSpec &net, const std::vector<uint8_t> &blob);
 
+// Size of this network's blob: a function of the topology alone (every rank of a multi-GPU job knows it
+// without having seen the parameter files).
+size_t blob_bytes(const NetSpec &net);
+
 // Sanity-check a blob received from elsewhere (e.g. an RCCL broadcast).
 std::string validate_blob(const NetSpec &net, const void *blob, size_t bytes);
 

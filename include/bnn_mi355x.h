@@ -96,6 +96,16 @@ int bnn_mi355x_set_device(int ordinal);
 size_t bnn_mi355x_pack_params(const char *path, void *dst, size_t cap);
 size_t bnn_mi355x_export_params(void *dst, size_t cap);
 int bnn_mi355x_import_params(const void *src, size_t bytes);
+/* params_bytes: the size of this network's blob -- a function of the topology alone, so every rank of a
+ *       multi-GPU job can allocate the receive buffer of the ONE broadcast without a size exchange.
+ * import_params_device: like import_params, but the blob lies in HBM (e.g. the tensor RCCL broadcast into);
+ *       d_src must be on this library's device, hip_stream is the stream that produced it (NULL = default).
+ *       The header is validated on the host before anything uses it.
+ * params_crc: CRC-32 of the parameter bytes the GPU holds (read back from HBM; 0 + last_error when nothing
+ *       is loaded): lets the ranks of a job prove that they classify with identical parameters. */
+size_t bnn_mi355x_params_bytes(void);
+int bnn_mi355x_import_params_device(const void *d_src, size_t bytes, void *hip_stream);
+unsigned int bnn_mi355x_params_crc(void);
 
 /* Classify n images held in HOST memory (n x image_bytes, same byte layout as
  * the bodies of the file formats).  Same return convention and ownership as
@@ -114,7 +124,14 @@ int bnn_mi355x_inference_raw(const uint8_t *images, int n_images, int16_t *score
  * decode); d_scores (CNV, optional): int16[n*64]; d_words (LFC, optional):
  * uint64[n].  All device pointers.  The workspace grows on demand (which
  * synchronises); call bnn_mi355x_reserve first to keep the call fully
- * asynchronous / graph-capturable.  Returns 0 on success. */
+ * asynchronous / graph-capturable.  Returns 0 on success.
+ * One activation workspace per library instance: calls are serialised on the device -- a call on another
+ * stream than the previous one first waits (hipStreamWaitEvent) for that call's kernels -- so they never
+ * race, but they do not overlap either; a captured graph must not be replayed concurrently with other calls
+ * into the same library.  The calling thread's current device is switched to this library's.
+ * LFC with d_classes: number_class <= 47 (the device decode is an exact floor(log2); the reference's
+ * (unsigned) log2((double) word) differs from it for some words of 48 and more bits, which only the host
+ * decode of inference_multiple / inference_buffer reproduces); take d_words beyond that. */
 int bnn_mi355x_inference_device(const void *d_images, int n_images, int number_class, int32_t *d_classes,
                                 int16_t *d_scores, uint64_t *d_words, void *hip_stream);
 int bnn_mi355x_reserve(int max_images);

@@ -38,3 +38,12 @@ def _build_oracle():
     import oracle_lib
     if not os.path.exists(os.path.join(oracle_lib.BUILD_DIR, "libbnn_oracle.so")):
         oracle_lib.build()
+
+
+@pytest.fixture(scope="session")
+def variant_libs():
+    """the hardened overlays' libraries (cnvW1A1-TMR, ...) are not part of the default build: `make variants`"""
+    import subprocess
+    lib = os.path.join(ROOT, "bnn-pynq_amd", "bnn", "libraries", "mi355x", "python_hw-lfcW1A2-interleaved-mi355x.so")
+    if not os.path.exists(lib):
+        subprocess.run(["make", "-s", "-j8", "-C", os.path.join(ROOT, "bnn-pynq_amd"), "variants"], check=True)

@@ -32,7 +32,8 @@ int main(int argc, char **argv) {
     // every fault mode, many faults: apply + re-pack the touched row (in-bounds reads/writes of raw and blob)
     for (int target = -1; target <= 1; target++)
       for (int ws : {1, 3, 8, 16}) {
-        const auto plan = plan_faults(net, 17 + ws, 1000, 400, ws, target, nullptr, 0);
+        std::vector<Fault> plan;
+        if (!plan_faults(net, 17 + ws, 1000, 400, ws, target, nullptr, 0, plan).empty()) return 1;
         for (const Fault &f : plan) {
           const int row = apply_fault(net, raw, f);
           if (row < 0) continue;

@@ -31,9 +31,22 @@ def test_header_declares_the_reference_cdef():
     assert sorted(gl.LEGACY + gl.EXT) == d
 
 
-@pytest.mark.parametrize("network", NETWORKS + VARIANTS)
+@pytest.mark.parametrize("network", NETWORKS)
 @pytest.mark.parametrize("runtime", ["python_sw", "python_hw"])
 def test_library_exports(network, runtime):
+    check_exports(network, runtime)
+
+
+@pytest.mark.parametrize("network", ["cnvW1A1-TMR", "lfcW1A2-interleaved"])
+def test_variant_library_exports(network, variant_libs):
+    """`make variants` (built on demand): the same ABI under the hardened overlays' names"""
+    check_exports(network, "python_sw")
+    for v in VARIANTS:
+        for rt in ("python_sw", "python_hw"):
+            assert os.path.exists(gl.lib_path(v, rt)), v
+
+
+def check_exports(network, runtime):
     path = gl.lib_path(network, runtime)
     assert os.path.exists(path), "build with `make -C bnn-pynq_amd`"
     lib = ctypes.CDLL(path)

@@ -198,3 +198,22 @@ def test_campaign_over_a_multi_chunk_file(tmp_path):
         start = end
     assert got.tolist() == want.tolist()
     L.load_parameters(pdir.encode())
+
+
+def test_planner_refuses_requests_it_cannot_honour():
+    """thresholds-only faults on layers without threshold memory, or a layer outside the network: an error,
+    not a campaign on something else under the same label (host-only entry point, no GPU needed)"""
+    import ctypes as C
+    L = gl.load("cnvW1A1")
+    rec = (C.c_int * 80)()
+    layers = (C.c_int * 1)(8)                                   # CNV layer 8: PassThroughActivation, no thresholds
+    assert L.bnn_mi355x_plan_faults(7, 100, 10, 1, 1, layers, 1, rec, 10) < 0
+    assert b"no threshold memory" in L.bnn_mi355x_last_error()
+    assert L.bnn_mi355x_plan_faults(7, 100, 10, 1, 0, layers, 1, rec, 10) == 10       # weights of layer 8: fine
+    assert all(rec[8 * i + 2] == 8 and rec[8 * i + 1] == 0 for i in range(10))
+    assert L.bnn_mi355x_plan_faults(7, 100, 10, 1, -1, layers, 1, rec, 10) == 10      # "any": only weights exist there
+    assert all(rec[8 * i + 1] == 0 for i in range(10))
+    for bad in (9, -1, 100):
+        layers[0] = bad
+        assert L.bnn_mi355x_plan_faults(7, 100, 10, 1, -1, layers, 1, rec, 10) < 0
+        assert b"out of range" in L.bnn_mi355x_last_error()

@@ -395,7 +395,7 @@ def test_file_abi_streams_multi_chunk_files(network, dataset, n, tmp_path):
 
 @pytest.mark.parametrize("variant,dataset", [("cnvW1A1-TMR", "cifar10"), ("cnvW2A2-resilient-interleaved", "cifar10"),
                                              ("lfcW1A2-interleaved", "mnist")])
-def test_hardened_variants_are_the_base_network(variant, dataset, tmp_path):
+def test_hardened_variants_are_the_base_network(variant, dataset, tmp_path, variant_libs):
     """cnvW1A1-TMR & co (bnn.py:41-53): same classes as the base network through the Python API; fault
     injection is refused for them (their memory organisation is not modelled), not silently approximated"""
     import sys
@@ -439,3 +439,127 @@ def test_layer0_integer_pipe_kernel_agrees():
     env = dict(os.environ, BNN_MI355X_L0="valu")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert "valu-l0-ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_layer0_threshold_above_the_trained_range_with_weights_of_minus_two(tmp_path):
+    """cnvW2A2 layer 0 under fault injection: a row of -2 weights reaches |dot| up to 2 * 27 * 128, and a
+    faulted threshold can lie above 27 * 128.  The matrix-pipe table clamps thresholds to the REACHABLE range
+    of the dot product, which depends on the weight range: rows 0..2 hold 14 x (-2) + 1 x (-1) taps, i.e.
+    dot = 3712 on an all-black picture (q = -128), against thresholds 4000 (must not fire), 3711 (fires) and
+    3712 (strict compare: does not).  Both forms of layer 0 against the faithful scalar restatement."""
+    import subprocess
+    import sys
+
+    import random_params
+    from bnn import params_io
+    from test_gpu_layers import stage_output, unpack
+    W, T = random_params.make(str(tmp_path), "cnvW2A2", 17)
+    for row, t in enumerate((4000, 3711, 3712)):
+        W[0][row, :] = 0
+        W[0][row, :14] = -2
+        W[0][row, 14] = -1
+        T[0][row, :] = (2 * t, 2 * t + 1)        # file units: 2^-8, accumulator = 2 * dot; blob threshold = floor(T / 2)
+    params_io.write_params(str(tmp_path), "cnvW2A2", W, T)
+    imgs = np.zeros((2, 3072), np.uint8)
+    imgs[1] = np.random.default_rng(3).integers(0, 256, 3072)
+    o = ol.Oracle("cnvW2A2", str(tmp_path))
+    want = [o.layer_ref(imgs[i], 0) for i in range(2)]
+    assert want[0].reshape(900, 64)[0, :3].tolist() == [-1, 1, -1]   # the crafted rows: no threshold, both, none
+    L = gl.load("cnvW2A2")
+    L.load_parameters(str(tmp_path).encode())
+    _nets.pop("cnvW2A2", None)
+    raw = stage_output(L, imgs, 0)
+    for i in range(2):
+        assert (unpack(raw[i], 900, 64, 2) == want[i]).all()
+    # the integer-pipe form of layer 0 (selected by the environment at load time): same bits
+    code = ("import sys, numpy as np; sys.path[:0] = [%r, %r]\n"
+            "import torch, gpu_lib as gl\nfrom test_gpu_layers import stage_output\n"
+            "L = gl.load('cnvW2A2'); L.load_parameters(%r.encode())\n"
+            "imgs = np.load(%r)\nnp.save(%r, stage_output(L, imgs, 0))\n"
+            % (os.path.join(gl.ROOT, "tests"), os.path.join(gl.ROOT, "bnn-pynq_amd"), str(tmp_path),
+               str(tmp_path / "imgs.npy"), str(tmp_path / "valu.npy")))
+    np.save(tmp_path / "imgs.npy", imgs)
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, BNN_MI355X_L0="valu"))
+    assert (np.load(tmp_path / "valu.npy") == raw).all()
+    L.load_parameters(gl.param_dir("cifar10", "cnvW2A2").encode())
+
+
+@pytest.mark.parametrize("network,dataset", [("lfcW1A1", "mnist"), ("lfcW1A2", "mnist"), ("lfcW1A1", "chars_merged")])
+def test_lfc_single_image_decode_on_words_with_several_bits(network, dataset, tmp_path):
+    """inference() on an LFC net decodes with round(log2(word)) and writes a 64-entry one-hot
+    (foldedmv-offload.cpp:152-165); the batched entry points use floor(log2) (:213-220).  The two differ exactly
+    when the word has more than one bit inside number_class, e.g. 0b1100 -> 4 vs 3 -- and the one-hot index can
+    then be a class that no neuron voted for.  Images are searched with the oracle until their output words
+    have >= 2 bits set and the two decodes disagree; both entry points are compared on them."""
+    net = gpu_net(network, dataset)
+    o = oracle(network, dataset)
+    ncls = ol.num_classes(dataset, network)
+    rng = np.random.default_rng(77)
+    found, tries = [], 0
+    while len(found) < 6 and tries < 40:
+        tries += 1
+        imgs = np.where(rng.random((4096, 784)) < rng.uniform(0.02, 0.6), rng.integers(128, 256, (4096, 784)), rng.integers(0, 128, (4096, 784))).astype(np.uint8)
+        words = o.words_fast(imgs)
+        mask = np.uint64((1 << ncls) - 1)
+        for i in np.flatnonzero([bin(int(w & mask)).count("1") >= 2 for w in words]):
+            w = int(words[i])
+            if o.L.bnn_oracle_decode_lfc_single(w, ncls) != o.L.bnn_oracle_decode_lfc_batched(w, ncls):
+                found.append((imgs[i].copy(), w))
+                if len(found) == 6:
+                    break
+    assert len(found) >= 3, "no multi-bit output words found"
+    res = (C.c_int * 64)()
+    usec = C.c_float(0)
+    for k, (img, w) in enumerate(found):
+        path = tmp_path / ("m%d.idx3" % k)
+        with open(path, "wb") as f:       # two images: inference() must classify the FIRST only
+            f.write((0x803).to_bytes(4, "big") + (2).to_bytes(4, "big") + (28).to_bytes(4, "big") * 2 + img.tobytes() + bytes(784))
+        cls = net.L.inference(str(path).encode(), res, ncls, C.byref(usec))
+        hot = o.L.bnn_oracle_lfc_single_hot(w, ncls)
+        assert cls == o.L.bnn_oracle_decode_lfc_single(w, ncls) == (hot if hot < 64 else 0)
+        assert list(res) == [1 if i == hot else 0 for i in range(64)]
+        cnt = C.c_int(0)
+        p = net.L.inference_multiple(str(path).encode(), ncls, C.byref(cnt), None, 0)
+        assert cnt.value == 2 and p[0] == o.L.bnn_oracle_decode_lfc_batched(w, ncls) != cls
+        net.L.free_results(p)
+        assert net.L.inference(str(path).encode(), None, ncls, None) == cls      # results may be NULL (bnn.py:133)
+
+
+def test_device_calls_on_two_streams_share_the_workspace_safely():
+    """bnn_mi355x_inference_device on alternating streams: one activation workspace per library, so a call must
+    first wait for the previous call's kernels on the other stream (include/bnn_mi355x.h); results equal the
+    single-stream ones and the oracle's.  Also: params_crc of what the GPU holds, import straight from HBM."""
+    import torch
+    net = gpu_net("cnvW1A1", "cifar10")
+    L = net.L
+    o = oracle("cnvW1A1", "cifar10")
+    n = 3000
+    batches = [rand_images("cnvW1A1", n, 900 + k) for k in range(4)]
+    dev = [torch.from_numpy(b).cuda() for b in batches]
+    out = [torch.full((n,), -1, dtype=torch.int32, device="cuda") for _ in range(4)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    assert L.bnn_mi355x_reserve(n) == 0
+    torch.cuda.synchronize()
+    for rep in range(3):
+        for k in range(4):
+            s = streams[k & 1]
+            assert L.bnn_mi355x_inference_device(dev[k].data_ptr(), n, 10, out[k].data_ptr(), None, None, s.cuda_stream) == 0
+    torch.cuda.synchronize()
+    for k in range(4):
+        assert (out[k].cpu().numpy() == o.classes_batched(batches[k], 10)).all(), k
+    # the blob as the GPU holds it: CRC equal to the host blob's, and importable from a device tensor
+    import zlib
+    size = L.bnn_mi355x_params_bytes()
+    host = np.zeros(size, np.uint8)
+    assert L.bnn_mi355x_export_params(host.ctypes.data, size) == size
+    assert L.bnn_mi355x_params_crc() == zlib.crc32(host.tobytes())
+    d_blob = torch.from_numpy(host).cuda()
+    assert L.bnn_mi355x_import_params_device(d_blob.data_ptr(), size, torch.cuda.current_stream().cuda_stream) == 0
+    assert L.bnn_mi355x_params_crc() == zlib.crc32(host.tobytes())
+    assert (net.classify(batches[0][:500], 10) == o.classes_batched(batches[0][:500], 10)).all()
+    bad = host.copy()
+    bad[24] ^= 0xFF                                                       # l0_mfma_offset
+    d_bad = torch.from_numpy(bad).cuda()
+    assert L.bnn_mi355x_import_params_device(d_bad.data_ptr(), size, None) != 0 and b"mismatch" in L.bnn_mi355x_last_error()
+    assert L.bnn_mi355x_import_params_device(d_blob.data_ptr(), size - 1, None) != 0
+    assert (net.classify(batches[1][:200], 10) == o.classes_batched(batches[1][:200], 10)).all()   # still loaded

@@ -98,18 +98,19 @@ def test_layer0_mfma_table(network, dataset):
     assert off and off % 256 == 0
     W = o.weights(0)
     nthr = 2 if network.endswith("A2") else 1
+    lim = 2 * 3456 if "W2" in network else 3456
     for which in range(2):
         A = blob[off + which * 2048: off + (which + 1) * 2048].copy().view(np.int8).reshape(64, 32)
         assert (A[:, :27] == W.reshape(64, 3, 3, 3).transpose(0, 3, 1, 2).reshape(64, 27)).all()
         assert (A[:, 29:] == 0).all()
         for n in range(64):
             t = o.L.bnn_oracle_threshold(o.h, 0, n, which if nthr == 2 else 0) >> 1
-            tc = min(3456, max(-3457, t))
+            tc = min(lim, max(-lim - 1, t))
             assert int(A[n, 27]) + 64 * int(A[n, 28]) == -tc - 1 and abs(int(A[n, 27])) <= 32
-    # clamping never changes a decision: |dot| <= 27 * 128
-    d = np.arange(-3456, 3457)
-    for t in (-(1 << 22), -3458, -3457, -3456, 0, 3455, 3456, 3457, 1 << 22):
-        tc = min(3456, max(-3457, t))
+    # clamping never changes a decision: |dot| <= 27 * 128 * max|w|  (ap_int<2> weights reach -2 under faults)
+    d = np.arange(-lim, lim + 1)
+    for t in (-(1 << 22), -lim - 2, -lim - 1, -lim, 0, lim - 1, lim, lim + 1, 1 << 22):
+        tc = min(lim, max(-lim - 1, t))
         assert ((t < d) == (tc < d)).all()
 
 
@@ -136,3 +137,30 @@ def test_missing_file_is_reported():
     L = gl.load("cnvW1A1")
     assert L.bnn_mi355x_pack_params(b"/nonexistent/dir", None, 0) == 0
     assert b"Could not open file" in L.bnn_mi355x_last_error()
+
+
+def test_import_rejects_headers_that_are_not_this_networks_layout():
+    """bnn_mi355x_import_params takes bytes from outside (broadcast, file): every header field is later used
+    as an offset or stride on the host and on the device, so each must be exactly what this library writes.
+    (On a GPU-less box a VALID blob gets as far as "no HIP device"; a corrupted one must fail before that.)"""
+    import ctypes as C
+    L = gl.load("cnvW2A2")
+    good = gl.pack_params("cnvW2A2", gl.param_dir("cifar10", "cnvW2A2"))
+    assert L.bnn_mi355x_params_bytes() == good.size
+
+    def error_for(blob):
+        rc = L.bnn_mi355x_import_params(blob.ctypes.data, blob.size)
+        return rc, L.bnn_mi355x_last_error().decode()
+
+    rc, err = error_for(good)
+    assert (rc == 0 and err == "") or "no HIP device" in err
+    hdr = 32  # magic0, magic1, version, net, nlayers, total_bytes, l0_mfma_offset, reserved; then 9 x {offset, row_dwords, rows, kw}
+    cases = {"l0_mfma_offset": (24, good.size), "kw of layer 1": (hdr + 16 * 1 + 12, 4096), "offset of layer 3": (hdr + 16 * 3, 4),
+             "rows of layer 8": (hdr + 16 * 8 + 8, 1 << 20), "row_dwords of layer 2": (hdr + 16 * 2 + 4, 3), "reserved": (28, 1)}
+    for what, (at, value) in cases.items():
+        bad = good.copy()
+        bad[at:at + 4] = np.frombuffer(struct.pack("<I", value), np.uint8)
+        rc, err = error_for(bad)
+        assert rc != 0 and "packed params" in err and "mismatch" in err, what
+    rc, err = error_for(good[:-256].copy())
+    assert rc != 0 and "size mismatch" in err
