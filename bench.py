@@ -71,6 +71,53 @@ def issue_floor_cycles(network):
     return cyc / 64.0                                # 64 lanes per wave instruction
 
 
+def measure_config(network, dataset, batch, dev, device_index, steps, warmup, check=2048):
+    """One more single-GPU BASELINE config through the same device-pointer entry point: images/s over `steps`
+    timed calls (inputs resident in HBM), HBM- and integer-issue fractions, and the classes of a bounded sample
+    compared with the CPU restatement (outside the timed region)."""
+    import oracle_lib as ol
+    is_cnv = network.startswith("cnv")
+    isz = 3072 if is_cnv else 784
+    L = gl.load(network)
+    assert L.bnn_mi355x_set_device(device_index) == 0 or L.bnn_mi355x_last_error()
+    L.load_parameters(gl.param_dir(dataset, network).encode())
+    err = L.bnn_mi355x_last_error().decode()
+    if err:
+        return {"error": err}
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    imgs = torch.randint(0, 256, (batch, isz), dtype=torch.uint8, device=dev, generator=g)
+    classes = torch.zeros(batch, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream()
+    assert L.bnn_mi355x_reserve(batch) == 0
+
+    def step():
+        if L.bnn_mi355x_inference_device(imgs.data_ptr(), batch, 10, classes.data_ptr(), None, None, stream.cuda_stream) != 0:
+            raise RuntimeError(L.bnn_mi355x_last_error().decode())
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    rate = batch / dt
+    k = min(check, batch)
+    o = ol.Oracle(network, ol.param_dir(dataset, network))
+    same = bool((classes[:k].cpu().numpy() == o.classes_batched(imgs[:k].cpu().numpy(), 10, host_cores())).all())
+    ceiling = N_SIMD * CLK_HZ / issue_floor_cycles(network)
+    alg = ALG_BYTES["cnv" if is_cnv else "lfc"]
+    L.deinit()
+    return {"workload": "%s, %d synthetic images per step, inputs resident in HBM" % (network, batch), "value": round(rate, 1),
+            "unit": "images/s", "us_per_step": round(dt * 1e6, 2), "steps": steps,
+            "roofline": {"bound": "hbm", "achieved": round(alg * rate / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg * rate / 1e9 / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_image": alg},
+            "valu": {"achieved": round(rate, 1), "peak": round(ceiling, 1), "unit": "images/s per GPU", "frac": round(rate / ceiling, 4)},
+            "classes_equal_oracle": same, "checked_images": k}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -134,7 +181,10 @@ def main():
     else:
         # rank 0 reads + repacks the files; the ~210 KB blob goes to the other GPUs over RCCL/xGMI:
         # the one collective of the whole job
+        dist.barrier()
+        tb = time.perf_counter()
         mg.distribute_params(L, pdir, device=None if a.rehearse_gloo else dev)
+        broadcast_ms = (time.perf_counter() - tb) * 1e3
 
     # ---- synthetic batch, resident in HBM before the timed region starts
     g = torch.Generator(device=dev)
@@ -168,10 +218,42 @@ def main():
     nchunks = C.c_int(0)
     nst = L.bnn_mi355x_profile_read(stage_ms, 16, C.byref(nchunks))
     L.bnn_mi355x_profile(0)
+    multi = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if a.rehearse_gloo else dev)
+        cdev = "cpu" if a.rehearse_gloo else dev
+        own_elapsed = elapsed
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # ---- self-validation of the N-rank run (all of it outside the timed region): every rank reports its own
+        # rate, how long its side of the broadcast took and the CRC-32 of the parameter bytes its GPU holds; the
+        # first 2048 images and classes of every rank go to rank 0, which classifies them with the CPU
+        # restatement from the parameter FILES (independent of the broadcast blob)
+        k = min(2048, a.batch)
+        mine = torch.tensor([a.batch * a.steps / own_elapsed, broadcast_ms, float(L.bnn_mi355x_params_crc())], dtype=torch.float64, device=cdev)
+        stats = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(stats, mine)
+        samp_i, samp_c = imgs[:k].to(cdev).contiguous(), classes[:k].to(cdev).contiguous()
+        gi = [torch.zeros_like(samp_i) for _ in range(world)] if rank == 0 else None
+        gc = [torch.zeros_like(samp_c) for _ in range(world)] if rank == 0 else None
+        dist.gather(samp_i, gi, dst=0)
+        dist.gather(samp_c, gc, dst=0)
+        if rank == 0:
+            crcs = ["%08x" % int(x[2].item()) for x in stats]
+            multi = {"ranks": world, "backend": "gloo (rehearsal: every rank on cuda:0)" if a.rehearse_gloo else "nccl (RCCL)",
+                     "per_rank_images_per_s": [round(float(x[0].item()), 1) for x in stats],
+                     "broadcast_ms": [round(float(x[1].item()), 3) for x in stats],
+                     "params_crc32": crcs, "params_identical_on_all_ranks": len(set(crcs)) == 1 and crcs[0] != "00000000",
+                     "collectives_on_the_data_path": 0}
+            if world <= 8:
+                import oracle_lib as ol
+                o = ol.Oracle(a.network, ol.param_dir(dataset, a.network))
+                ok = [bool((gc[r].cpu().numpy() == o.classes_batched(gi[r].cpu().numpy(), ncls, host_cores())).all()) for r in range(world)]
+                multi["first_%d_classes_of_every_rank_equal_oracle" % k] = ok
+                if not all(ok) or not multi["params_identical_on_all_ranks"]:
+                    print(json.dumps({"error": "multi-GPU self-check failed", "multi_gpu": multi}))
+                    dist.destroy_process_group()
+                    sys.exit("PARITY FAILURE in the %d-rank run" % world)
 
     if rank != 0:
         if world > 1:
@@ -189,11 +271,13 @@ def main():
     dev_ms = sum(per_stage)
     alg = ALG_BYTES["cnv" if is_cnv else "lfc"]
     achieved = alg * a.batch / (dev_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_source = None, None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf):
         try:
             t = json.load(open(tf)).get(a.network, {})
+            traffic_source = ("profiles/traffic.json: FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE per image from the builder's "
+                              "two rocprofv3 --pmc passes (%s), scaled to this launch; not re-measured in this run" % t.get("source", "profiles/"))
             # measured HBM bytes per image (PMC passes, profiles/) x the images of one launch
             traffic = int((t["fetch_bytes_per_image_x2"] + t["write_bytes_per_image"]) * imgs_per_launch)
         except Exception:
@@ -210,7 +294,7 @@ def main():
                          "achieved": round(dom_alg * a.batch / (per_stage[dom] * 1e-3) / 1e9, 2), "unit": "GB/s",
                          "frac": round(dom_alg * a.batch / (per_stage[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)})
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
                 "kernel": "all %d stages of one batch (dominant: %s, %.1f%% of device time)" % (
                     nst, names[dom], 100.0 * per_stage[dom] / dev_ms),
                 "algorithmic_bytes_per_image": alg, "images_per_launch": int(imgs_per_launch),
@@ -225,6 +309,8 @@ def main():
                       % (a.network, a.batch, "32x32x3 uint8" if is_cnv else "28x28 uint8", dataset, a.network),
                       "images_per_gpu_per_step": a.batch, "parallelism": "dp%d (batch shards, no data-path collective)" % world},
            "roofline": roofline}
+    if multi:
+        out["multi_gpu"] = multi
     floor_cyc = issue_floor_cycles(a.network)
     ceiling = N_SIMD * CLK_HZ / floor_cyc            # images/s per GPU at the issue floor
     per_gpu = a.batch / (dev_ms * 1e-3)
@@ -293,6 +379,18 @@ def main():
             L.bnn_mi355x_import_params(blob.ctypes.data, size)
             step()
             torch.cuda.synchronize()
+
+    # ---- the other single-GPU BASELINE configs (2: LFC-W1A1 at its quoted 10 000-image batch; 4: CNV-W2A2), outside
+    # the timed region of `value`: a few ms of GPU time each, classes of a sample checked against the oracle
+    if world == 1 and not a.no_extras and a.network == "cnvW1A1":
+        out["other_configs"] = {
+            "lfcW1A1_10000": measure_config("lfcW1A1", "mnist", 10000, dev, local_rank, 300, 20),
+            "lfcW1A1_131072": measure_config("lfcW1A1", "mnist", 131072, dev, local_rank, 40, 5),
+            "cnvW2A2_131072": measure_config("cnvW2A2", "cifar10", 131072, dev, local_rank, 8, 2),
+        }
+        if not all(v.get("classes_equal_oracle") for v in out["other_configs"].values()):
+            print(json.dumps(out))
+            sys.exit("PARITY FAILURE in other_configs")
 
     # ---- CPU baseline: the CPU restatement on this host's cores, bounded sample, same images
     if world == 1 and not a.no_cpu_baseline:

@@ -13,6 +13,8 @@ struct CnvLaunch {
   void *buf0, *buf1;          // device ping-pong activation buffers (cnv_workspace_bytes per image)
   const uint32_t *rows[9];    // device, per-layer packed rows (packed_params.h)
   const uint8_t *l0_mfma;     // device, layer-0 MFMA table (packed_params.h); null: integer-pipe k_conv0
+  const uint8_t *l1_mfma;     // device, cnvW1A1 layer 1 as FP4 MFMA operands (l1_mfma_table); null: the XNOR-popcount kernel.
+                              // Side experiment only (BNN_MI355X_L1=mfma): never the default path.
   bool has_two;               // cnvW2A2: some row holds a weight of -2 (fault injection): the -2-aware kernel variants
   int16_t *scores;            // device, n x 64, may be null
   int32_t *classes;           // device, n, may be null
@@ -42,6 +44,14 @@ const char *stage_name(bool is_cnv, int stage);
 size_t stage_output_bytes(bool is_cnv, int abits, int stage, int *in_buf1);
 void cnv_workspace_bytes(int abits, size_t *buf0, size_t *buf1);
 void lfc_workspace_bytes(int abits, size_t *buf0, size_t *buf1);
+
+// cnvW1A1 layer 1 for the matrix pipe (side experiment): A operands of v_mfma_scale_f32_32x32x64_f8f6f4 with
+// FP4 (E2M1) weights -- +1 = 0x2, -1 = 0xA -- [tap 0..8][neuron tile 0..1][lane 0..63][16 bytes], lane (r, h)
+// holding channels 32h..32h+31 of neuron 32*tile + r; then the accumulator seeds [tile][h][16] floats
+// -(theta + 1) with theta = 576 - 2 * t the threshold on the signed sum (the row's t is the XNOR form's
+// "mismatches < t").  rows: layer 1 of the packed blob (host pointer).  Returns the table's bytes.
+constexpr size_t kL1MfmaWeights = 9 * 2 * 64 * 16, kL1MfmaBytes = kL1MfmaWeights + 2 * 2 * 16 * 4;
+void l1_mfma_table(const uint32_t *rows, uint8_t *dst);
 
 // enqueue all stages of one batch on a.stream; returns the launch error, if any
 hipError_t run_cnv(NetId net, const CnvLaunch &a);

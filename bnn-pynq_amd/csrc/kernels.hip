@@ -354,6 +354,104 @@ __global__ __launch_bounds__(kBlock) void k_conv0_mfma(const uint8_t *__restrict
 }
 
 // ---------------------------------------------------------------------------
+// SIDE EXPERIMENT, not the product path (BNN_MI355X_L1=mfma; DESIGN.md 5 "Pricing the rule"): cnvW1A1 layer 1
+// -- 46 % of the network's time on the integer pipe -- as an implicit GEMM on the matrix cores.  The north-star
+// rules the matrix pipe out for the bitwise layers; this kernel exists to put a measured number next to that
+// rule, bit-exact like everything else.
+//   D[neuron][pixel] = sum over 9 taps x 64 channels of w * a,  w, a in {-1, +1} as FP4 E2M1 (0x2 / 0xA): exact
+//   in f32 (|D| <= 576).  v_mfma_scale_f32_32x32x64_f8f6f4: 32 neurons x 32 pixels x one tap (64 channels) per
+//   instruction, 65 536 MACs in 32 SIMD-cycles -- 6.3x the 64 lanes x 32 synapses / 6.3 cycles of xor + bcnt.
+// A block (256 threads) takes two images at a time: their bit-packed 30x30x64 maps are expanded once into FP4
+// planes in LDS ([image][channel half h][pixel] x 16 bytes: the B operand of lane (pixel column c, h) is one
+// ds_read_b128, conflict-free); the 18 KB of FP4 weights stay in 72 VGPRs of every wave.  A wave owns a PAIR of
+// output rows (2r, 2r+1) x 28 columns (lanes c = 28..31 idle: 87.5 % of the tile) x all 64 neurons: 36 MFMAs,
+// accumulators seeded with -(theta + 1) so that the result's sign bit is !fire; vertical max-pool = AND of the
+// two rows' !fire words in the lane, horizontal = AND with lane c ^ 1 (DPP), 14 pooled pixels stored per pair.
+// ---------------------------------------------------------------------------
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+constexpr int kL1Pix = 912;  // pixels per LDS plane: 900 + what the idle lanes' windows overrun
+
+// 8 bits -> 8 FP4 nibbles, bit i -> nibble i: 1 -> 0x2 (+1.0), 0 -> 0xA (-1.0)
+__device__ __forceinline__ uint32_t fp4_pm1(uint32_t byte) {
+  uint32_t t = ~byte & 0xFFu;                 // 1 where the activation is -1
+  t = (t | (t << 12)) & 0x000F000Fu;
+  t = (t | (t << 6)) & 0x03030303u;
+  t = (t | (t << 3)) & 0x11111111u;
+  return (t << 3) + 0x22222222u;              // 0x2 + 8 * [-1]
+}
+
+__global__ __launch_bounds__(256, 2) void k_l1_mfma(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                     const uint8_t *__restrict__ tab, int n_images) {
+  __shared__ uint4 plane[2][2][kL1Pix];  // [image of the pair][h][pixel]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5;
+  // weights: 9 taps x 2 neuron tiles, 16 bytes each, for the whole kernel
+  const uint4 *__restrict__ wt = reinterpret_cast<const uint4 *>(tab);
+  v8i wreg[9][2];
+#pragma unroll
+  for (int tap = 0; tap < 9; tap++)
+#pragma unroll
+    for (int mt = 0; mt < 2; mt++) {
+      const uint4 v = wt[(tap * 2 + mt) * 64 + lane];
+      wreg[tap][mt] = v8i{(int)v.x, (int)v.y, (int)v.z, (int)v.w, 0, 0, 0, 0};
+    }
+  const float *__restrict__ seeds = reinterpret_cast<const float *>(tab + kL1MfmaWeights);
+  v16f seed[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) seed[mt][i] = seeds[(mt * 2 + h) * 16 + i];
+  const int cc = c < 28 ? c : 27;  // idle lanes repeat column 27 (their results are dropped)
+  for (int pair = blockIdx.x; pair * 2 < n_images; pair += gridDim.x) {
+    const int img0 = pair * 2, nimg = min(2, n_images - img0);
+    __syncthreads();  // the previous pair's planes are no longer read
+    for (int d = tid; d < nimg * 1800; d += 256) {  // one source dword (32 channels of a pixel) per iteration
+      const int i = d / 1800, e = d - i * 1800, pix = e >> 1, hh = e & 1;
+      const uint32_t bits = in[(size_t)(img0 + i) * 1800 + e];
+      plane[i][hh][pix] = make_uint4(fp4_pm1(bits), fp4_pm1(bits >> 8), fp4_pm1(bits >> 16), fp4_pm1(bits >> 24));
+    }
+    __syncthreads();
+    for (int rp = wave; rp < nimg * 14; rp += 4) {  // row pair (2r, 2r+1) of image i
+      const int i = rp / 14, r = rp - i * 14;
+      const uint4 *__restrict__ P = &plane[i][h][0];
+      v16f acc[2][2] = {{seed[0], seed[0]}, {seed[1], seed[1]}};  // [neuron tile][row of the pair]
+#pragma unroll
+      for (int kx = 0; kx < 3; kx++) {
+        v8i b[4];  // input rows 2r .. 2r+3 at column c + kx
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+          const uint4 v = P[(2 * r + y) * 30 + cc + kx];
+          b[y] = v8i{(int)v.x, (int)v.y, (int)v.z, (int)v.w, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+          for (int mt = 0; mt < 2; mt++)
+#pragma unroll
+            for (int pt = 0; pt < 2; pt++)
+              acc[mt][pt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wreg[ky * 3 + kx][mt], b[ky + pt], acc[mt][pt], 4, 4, 0,
+                                                                              0x7F7F7F7F, 0, 0x7F7F7F7F);
+      }
+      uint32_t word[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; mt++) {
+        int v0[16], v1[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+          v0[k] = __float_as_int(acc[mt][0][k]);
+          v1[k] = __float_as_int(acc[mt][1][k]);
+        }
+        const uint32_t nf = or_halves(sign_nibbles(v0, h) & sign_nibbles(v1, h));  // !fire of both rows, 32 neurons
+        const uint32_t pooled = nf & (uint32_t)__builtin_amdgcn_mov_dpp((int)nf, 0xB1, 0xF, 0xF, true);  // & lane c ^ 1
+        word[mt] = ~pooled;
+      }
+      if (h == 0 && c < 28 && !(c & 1))
+        *reinterpret_cast<uint2 *>(out + ((size_t)(img0 + i) * 196 + r * 14 + (c >> 1)) * 2) = make_uint2(word[0], word[1]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // AR_XNOR, 1-bit out: the headline path (cnvW1A1 layers 1..7, lfcW1A1).
 // Measured on MI355X (profiles/r01_microbench*.txt): v_xor_b32 and
 // v_bcnt_u32_b32 both go down the integer pipe, ~4.2 cycles per wave64
@@ -369,39 +467,30 @@ __global__ __launch_bounds__(kBlock) void k_conv0_mfma(const uint8_t *__restrict
 //     result word with one v_alignbit_b32 (no v_cmp / v_cndmask / v_or);
 //     channels are walked 31..0 so that channel c lands on bit c.
 // ---------------------------------------------------------------------------
-#ifndef BNN_XPOP_STYLE
-#define BNN_XPOP_STYLE 1  // measured: 0 -> 6.13 ms, 1 -> 5.05 ms, 2 -> 5.88 ms for CNV layer 1 at 131072 images
-#endif
-__device__ __forceinline__ void xpop(int &acc, uint32_t w, uint32_t a) {
-#if BNN_XPOP_STYLE == 1
+// One (v_xor, v_bcnt) pair per asm statement.  `t` is ONE scratch VGPR threaded through every statement of a
+// kernel as an in/out operand: that (false) dependency keeps the statements in source order -- the pairs of
+// the four accumulators strictly alternate -- and makes each statement touch a VGPR the previous one defined,
+// which is exactly the condition under which the compiler puts one `s_nop 0` between them.  (op, bcnt, nop)
+// issues in 6.3 cycles, the same pairs back to back in 8.0 (profiles/r01_microbench9_nop_cadence.txt); the
+// built code object is checked for this stream by tools/check_cadence.py (tests/test_kernel_cadence.py).
+__device__ __forceinline__ uint32_t chain_temp() {
   uint32_t t;
-  asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "=&v"(t), "+v"(acc) : "s"(w), "v"(a));
-#else
-  acc = __builtin_popcount(w ^ a) + acc;
-  asm("" : "+v"(acc));
-#endif
+  asm("" : "=v"(t));  // any value: every statement overwrites it before reading it
+  return t;
+}
+__device__ __forceinline__ void xpop(int &acc, uint32_t w, uint32_t a, uint32_t &t) {
+  asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "+v"(t), "+v"(acc) : "s"(w), "v"(a));
 }
 // four accumulators against one weight dword, strictly alternating xor / bcnt
 __device__ __forceinline__ void xpop4(int &m0, int &m1, int &m2, int &m3, uint32_t w, uint32_t a0, uint32_t a1,
-                                      uint32_t a2, uint32_t a3) {
-#if BNN_XPOP_STYLE == 2
-  uint32_t t0, t1;
-  asm("v_xor_b32 %0, %6, %7\n\tv_bcnt_u32_b32 %2, %0, %2\n\t"
-      "v_xor_b32 %1, %6, %8\n\tv_bcnt_u32_b32 %3, %1, %3\n\t"
-      "v_xor_b32 %0, %6, %9\n\tv_bcnt_u32_b32 %4, %0, %4\n\t"
-      "v_xor_b32 %1, %6, %10\n\tv_bcnt_u32_b32 %5, %1, %5"
-      : "=&v"(t0), "=&v"(t1), "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3)
-      : "s"(w), "v"(a0), "v"(a1), "v"(a2), "v"(a3));
-#else
-  xpop(m0, w, a0); xpop(m1, w, a1); xpop(m2, w, a2); xpop(m3, w, a3);
-#endif
+                                      uint32_t a2, uint32_t a3, uint32_t &t) {
+  xpop(m0, w, a0, t); xpop(m1, w, a1, t); xpop(m2, w, a2, t); xpop(m3, w, a3, t);
 }
 // first pair of a chain: the accumulator starts at `seed` (an SGPR: -threshold, so that the chain ends on
 // m - t and the compare costs neither a v_mov 0 nor a subtract)
-__device__ __forceinline__ int xpop_seed(uint32_t w, uint32_t a, int seed) {
-  uint32_t t;
+__device__ __forceinline__ int xpop_seed(uint32_t w, uint32_t a, int seed, uint32_t &t) {
   int acc;
-  asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %4" : "=&v"(t), "=v"(acc) : "s"(w), "v"(a), "s"(seed));
+  asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %4" : "+v"(t), "=v"(acc) : "s"(w), "v"(a), "s"(seed));
   return acc;
 }
 // result of one neuron group of one pixel/vector: a whole dword (32 neurons per block, the
@@ -434,6 +523,7 @@ __global__ __launch_bounds__(kBlock) void k_quad_x(const uint64_t *__restrict__ 
         wl[y][x][k] = (uint32_t)v;
         wh[y][x][k] = (uint32_t)(v >> 32);
       }
+  uint32_t t = chain_temp();
   for (int cg = bm.cg * gpb, cg_end = cg + gpb; cg < cg_end; cg++) {  // see k_conv0
     kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)cg * NPB * ROW_DW);
     uint32_t b[4] = {0, 0, 0, 0};
@@ -447,11 +537,11 @@ __global__ __launch_bounds__(kBlock) void k_quad_x(const uint64_t *__restrict__ 
         const uint32_t w0 = r[2 + 2 * j], w1 = r[3 + 2 * j];
         if (j == 0) {
   #pragma unroll
-          for (int i = 0; i < 4; i++) m[i >> 1][i & 1] = xpop_seed(w0, wl[ky + (i >> 1)][kx + (i & 1)][k], nt);
+          for (int i = 0; i < 4; i++) m[i >> 1][i & 1] = xpop_seed(w0, wl[ky + (i >> 1)][kx + (i & 1)][k], nt, t);
         } else {
-          xpop4(m[0][0], m[0][1], m[1][0], m[1][1], w0, wl[ky][kx][k], wl[ky][kx + 1][k], wl[ky + 1][kx][k], wl[ky + 1][kx + 1][k]);
+          xpop4(m[0][0], m[0][1], m[1][0], m[1][1], w0, wl[ky][kx][k], wl[ky][kx + 1][k], wl[ky + 1][kx][k], wl[ky + 1][kx + 1][k], t);
         }
-        xpop4(m[0][0], m[0][1], m[1][0], m[1][1], w1, wh[ky][kx][k], wh[ky][kx + 1][k], wh[ky + 1][kx][k], wh[ky + 1][kx + 1][k]);
+        xpop4(m[0][0], m[0][1], m[1][0], m[1][1], w1, wh[ky][kx][k], wh[ky][kx + 1][k], wh[ky + 1][kx][k], wh[ky + 1][kx + 1][k], t);
       }
       if constexpr (POOL) {  // OR of the four fire bits == (min (m - t)) < 0
         b[0] = shift_in_sign(b[0], min(min(m[0][0], m[0][1]), min(m[1][0], m[1][1])));
@@ -523,20 +613,21 @@ __global__ __launch_bounds__(kBlock) void k_vec_x(const uint64_t *__restrict__ i
       ah[k] = (uint32_t)(v >> 32);
     }
   }
+  uint32_t t = chain_temp();
   for (int cg = bm.cg * gpb, cg_end = cg + gpb; cg < cg_end; cg++) {  // see k_conv0
     kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)cg * NPB * ROW_DW);
     uint32_t b = 0;
     for (int c = NPB - 1; c >= 0; c -= 2) {
       kptr32 r1 = w + c * ROW_DW, r0 = r1 - ROW_DW;
-      int m1 = xpop_seed(r1[2], al[0], -(int)r1[0]), m0 = xpop_seed(r0[2], al[0], -(int)r0[0]);
-      xpop(m1, r1[3], ah[0]);
-      xpop(m0, r0[3], ah[0]);
+      int m1 = xpop_seed(r1[2], al[0], -(int)r1[0], t), m0 = xpop_seed(r0[2], al[0], -(int)r0[0], t);
+      xpop(m1, r1[3], ah[0], t);
+      xpop(m0, r0[3], ah[0], t);
   #pragma unroll
       for (int k = 1; k < KW; k++) {
-        xpop(m1, r1[2 + 2 * k], al[k]);
-        xpop(m0, r0[2 + 2 * k], al[k]);
-        xpop(m1, r1[3 + 2 * k], ah[k]);
-        xpop(m0, r0[3 + 2 * k], ah[k]);
+        xpop(m1, r1[2 + 2 * k], al[k], t);
+        xpop(m0, r0[2 + 2 * k], al[k], t);
+        xpop(m1, r1[3 + 2 * k], ah[k], t);
+        xpop(m0, r0[3 + 2 * k], ah[k], t);
       }
       b = shift_in_sign(b, m1);
       b = shift_in_sign(b, m0);
@@ -570,33 +661,50 @@ __global__ __launch_bounds__(kBlock) void k_vec_x(const uint64_t *__restrict__ i
 
 // one 32-bit half of a weight word against one 32-bit half of an activation word.
 // wq: this word's weight dwords {lo, hi} (XNOR, TB) or {sign lo, sign hi, nz lo, nz hi} (TT)
-template <int ARITH>
-__device__ __forceinline__ void mac32(int &m, int &z, uint32_t as, uint32_t az, kptr32 wq, int half) {
-  uint32_t t0, t1;
+// FIRST: the first statement of a chain -- the accumulator is WRITTEN, not read: v_bcnt's addend is the seed
+// (XNOR: -t0 from an SGPR, so that the chain ends on m - t0; the ternary forms: the inline constant 0), which
+// saves the v_mov 0 per accumulator and neuron that an initialised C variable costs.
+// Every (logic op, v_bcnt) pair is its own asm statement: the s_nop 0 that ends up behind each of them is what
+// lets the SIMD alternate between waves at the right cadence -- (op, bcnt, s_nop 0) issues in 6.3 cycles, the
+// same pairs back to back in 8.0 (profiles/r01_microbench9_nop_cadence.txt).  The compiler puts that nop behind
+// an asm statement whenever the next instruction touches one of its VGPR results: the scratch register `t`
+// (chain_temp) is threaded through all statements for that reason, and to pin their order.
+// tools/check_cadence.py verifies the result in the built code object (tests/test_kernel_cadence.py): a
+// toolchain that changes the habit fails the build check instead of silently costing 20 %.
+template <int ARITH, bool FIRST = false>
+__device__ __forceinline__ void mac32(int &m, int &z, uint32_t as, uint32_t az, kptr32 wq, int half, uint32_t &t, int seed = 0) {
   if constexpr (ARITH == AR_XNOR) {
-    asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "=&v"(t0), "+v"(m) : "s"(wq[half]), "v"(as));
+    if constexpr (FIRST) asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %4" : "+v"(t), "=v"(m) : "s"(wq[half]), "v"(as), "s"(seed));
+    else asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "+v"(t), "+v"(m) : "s"(wq[half]), "v"(as));
   } else if constexpr (ARITH == AR_TB) {
-    asm("v_bitop3_b32 %0, %2, %3, %4 bitop3:" BNN_BITOP_AND_XOR "\n\tv_bcnt_u32_b32 %1, %0, %1"
-        : "=&v"(t0), "+v"(m)
-        : "s"(wq[half]), "v"(as), "v"(az));
+    if constexpr (FIRST)
+      asm("v_bitop3_b32 %0, %2, %3, %4 bitop3:" BNN_BITOP_AND_XOR "\n\tv_bcnt_u32_b32 %1, %0, 0"
+          : "+v"(t), "=v"(m)
+          : "s"(wq[half]), "v"(as), "v"(az));
+    else
+      asm("v_bitop3_b32 %0, %2, %3, %4 bitop3:" BNN_BITOP_AND_XOR "\n\tv_bcnt_u32_b32 %1, %0, %1"
+          : "+v"(t), "+v"(m)
+          : "s"(wq[half]), "v"(as), "v"(az));
   } else {
-    // two statements, not one: the s_nop 0 the compiler puts behind every inline-asm statement is what lets
-    // the SIMD alternate between waves at the right cadence -- (op, bcnt, s_nop 0) issues in 6.3 cycles, the
-    // four instructions back to back in 14.2 instead of 12.7 (profiles/r01_microbench9_nop_cadence.txt)
-    asm("v_and_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "=&v"(t0), "+v"(z) : "s"(wq[2 + half]), "v"(az));
-    // (behind the first statement the compiler adds the s_nop itself -- the next one reads t0 --, behind the
-    // second it does not: written out)
-    asm("v_bitop3_b32 %0, %2, %3, %4 bitop3:" BNN_BITOP_AND_XOR "\n\tv_bcnt_u32_b32 %1, %0, %1\n\ts_nop 0"
-        : "=&v"(t1), "+v"(m)
-        : "s"(wq[half]), "v"(as), "v"(t0));
+    // z += popc(za & zw), then m += popc((za & zw) & (sa ^ sw)): the second statement works on t in place
+    if constexpr (FIRST) {
+      asm("v_and_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, 0" : "+v"(t), "=v"(z) : "s"(wq[2 + half]), "v"(az));
+      asm("v_bitop3_b32 %0, %2, %3, %0 bitop3:" BNN_BITOP_AND_XOR "\n\tv_bcnt_u32_b32 %1, %0, 0" : "+v"(t), "=v"(m) : "s"(wq[half]), "v"(as));
+    } else {
+      asm("v_and_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "+v"(t), "+v"(z) : "s"(wq[2 + half]), "v"(az));
+      asm("v_bitop3_b32 %0, %2, %3, %0 bitop3:" BNN_BITOP_AND_XOR "\n\tv_bcnt_u32_b32 %1, %0, %1" : "+v"(t), "+v"(m) : "s"(wq[half]), "v"(as));
+    }
   }
 }
 
+// The quantity the thresholds are compared with, d = sum of w*a over the window (the reference's accumulator):
+//   AR_XNOR: the chain was seeded with -t0, so m IS the decision value g0 = m - t0 (fire0 <=> g0 < 0)
+//   AR_TB:   d = nz - 2m     AR_TT:   d = z - 2m        one v_mad_i32_i24 (m * -2 + zz), fire_i <=> t_i - d < 0
 template <int ARITH>
-__device__ __forceinline__ int q_of(int m, int z, int neg_nzt) {
-  if constexpr (ARITH == AR_XNOR) return m;
-  else if constexpr (ARITH == AR_TB) return (m << 1) + neg_nzt;
-  else return (m << 1) - z;
+__device__ __forceinline__ int d_of(int m, int zz) {
+  int d;  // (written out: LLVM would turn m * -2 + zz into a shift and a subtract, two issue slots)
+  asm("v_mad_i32_i24 %0, %1, -2, %2" : "=v"(d) : "v"(m), "v"(zz));
+  return d;
 }
 
 // shift the decision(s) into the result word(s).  1-bit out: fire0.  2-bit out: b0 collects fire0
@@ -644,7 +752,7 @@ __global__ __launch_bounds__(kBlock) void k_quad(const uint64_t *__restrict__ in
           wz[y][x][k][0] = (uint32_t)u; wz[y][x][k][1] = (uint32_t)(u >> 32);
         }
       }
-  // AR_TB: minus the number of non-zero activations in each of the 4 windows (weight independent)
+  // AR_TB: the number of non-zero activations in each of the 4 windows (weight independent)
   int nn[2][2] = {{0, 0}, {0, 0}};
   if constexpr (ARITH == AR_TB) {
 #pragma unroll
@@ -657,15 +765,16 @@ __global__ __launch_bounds__(kBlock) void k_quad(const uint64_t *__restrict__ in
           for (int kx = 0; kx < 3; kx++)
 #pragma unroll
             for (int k = 0; k < CW; k++)
-              nn[dy][dx] -= __builtin_popcount(wz[dy + ky][dx + kx][k][0]) + __builtin_popcount(wz[dy + ky][dx + kx][k][1]);
+              nn[dy][dx] += __builtin_popcount(wz[dy + ky][dx + kx][k][0]) + __builtin_popcount(wz[dy + ky][dx + kx][k][1]);
   }
+  uint32_t t = chain_temp();
   for (int cg = bm.cg * gpb, cg_end = cg + gpb; cg < cg_end; cg++) {  // see k_conv0
     kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)cg * NPB * ROW_DW);
     uint32_t b0[4] = {0, 0, 0, 0}, b1[4] = {0, 0, 0, 0};
     for (int c = NPB - 1; c >= 0; c--) {
       kptr32 r = w + c * ROW_DW;
       const int t0 = (int)r[0], t1 = (int)r[1];
-      const int c0 = (ARITH == AR_XNOR) ? -t0 : t0, dt = (ARITH == AR_XNOR) ? (t0 - t1) : (t1 - t0);
+      // (the zeros are never materialised: the first statement of each chain writes its accumulator)
       int m[2][2] = {{0, 0}, {0, 0}}, z[2][2] = {{0, 0}, {0, 0}};
   #pragma unroll
       for (int j = 0; j < KW; j++) {
@@ -676,8 +785,11 @@ __global__ __launch_bounds__(kBlock) void k_quad(const uint64_t *__restrict__ in
   #pragma unroll
           for (int dy = 0; dy < 2; dy++)
   #pragma unroll
-            for (int dx = 0; dx < 2; dx++)
-              mac32<ARITH>(m[dy][dx], z[dy][dx], ws[dy + ky][dx + kx][k][h], wz[dy + ky][dx + kx][PL == 2 ? k : 0][h], wq, h);
+            for (int dx = 0; dx < 2; dx++) {
+              const uint32_t as = ws[dy + ky][dx + kx][k][h], az = wz[dy + ky][dx + kx][PL == 2 ? k : 0][h];
+              if (j == 0 && h == 0) mac32<ARITH, true>(m[dy][dx], z[dy][dx], as, az, wq, h, t, -t0);
+              else mac32<ARITH>(m[dy][dx], z[dy][dx], as, az, wq, h, t);
+            }
       }
       if constexpr (TWO) {
         if (r[2 + 6 * KW]) {  // this neuron has weights of -2 (fault injection only)
@@ -695,14 +807,24 @@ __global__ __launch_bounds__(kBlock) void k_quad(const uint64_t *__restrict__ in
           }
         }
       }
-      if constexpr (POOL) {
-        const int q0 = q_of<ARITH>(m[0][0], z[0][0], nn[0][0]), q1 = q_of<ARITH>(m[0][1], z[0][1], nn[0][1]);
-        const int q2 = q_of<ARITH>(m[1][0], z[1][0], nn[1][0]), q3 = q_of<ARITH>(m[1][1], z[1][1], nn[1][1]);
-        decide<OUT2>(b0[0], b1[0], min(min(q0, q1), min(q2, q3)) + c0, dt);
-      } else {
+      // decision values: g0 < 0 <=> the first threshold fires, g1 = g0 + dt likewise for the second
+      if constexpr (ARITH == AR_XNOR) {  // chains seeded with -t0: m is g0 already; max-pool = min over the quad
+        if constexpr (POOL) {
+          decide<OUT2>(b0[0], b1[0], min(min(m[0][0], m[0][1]), min(m[1][0], m[1][1])), t0 - t1);
+        } else {
   #pragma unroll
-        for (int i = 0; i < 4; i++)
-          decide<OUT2>(b0[i], b1[i], q_of<ARITH>(m[i >> 1][i & 1], z[i >> 1][i & 1], nn[i >> 1][i & 1]) + c0, dt);
+          for (int i = 0; i < 4; i++) decide<OUT2>(b0[i], b1[i], m[i >> 1][i & 1], t0 - t1);
+        }
+      } else {  // d = sum of w*a; fire_i <=> t_i - d < 0; max-pool = max of d over the quad
+        int d[4];
+  #pragma unroll
+        for (int i = 0; i < 4; i++) d[i] = d_of<ARITH>(m[i >> 1][i & 1], ARITH == AR_TB ? nn[i >> 1][i & 1] : z[i >> 1][i & 1]);
+        if constexpr (POOL) {
+          decide<OUT2>(b0[0], b1[0], t0 - max(max(d[0], d[1]), max(d[2], d[3])), t1 - t0);
+        } else {
+  #pragma unroll
+          for (int i = 0; i < 4; i++) decide<OUT2>(b0[i], b1[i], t0 - d[i], t1 - t0);
+        }
       }
     }
     if constexpr (POOL) {
@@ -769,23 +891,31 @@ __global__ __launch_bounds__(kBlock) void k_vec(const uint64_t *__restrict__ in,
 #pragma unroll
     for (int k = 0; k < KW; k++) load_word(k, base + k * PL);
   }
-  int nn = 0;
+  int nn = 0;  // AR_TB: non-zero activations of the vector
   if constexpr (ARITH == AR_TB) {
 #pragma unroll
-    for (int k = 0; k < KW; k++) nn -= __builtin_popcount(az[k][0]) + __builtin_popcount(az[k][1]);
+    for (int k = 0; k < KW; k++) nn += __builtin_popcount(az[k][0]) + __builtin_popcount(az[k][1]);
   }
+  uint32_t t = chain_temp();
   for (int cg = bm.cg * gpb, cg_end = cg + gpb; cg < cg_end; cg++) {  // see k_conv0
     kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)cg * NPB * ROW_DW);
     uint32_t b0 = 0, b1 = 0;
     for (int c = NPB - 1; c >= 0; c -= 2) {
       kptr32 rA = w + c * ROW_DW, rB = rA - ROW_DW;
-      int mA = 0, zA = 0, mB = 0, zB = 0;
+      const int tA0 = (int)rA[0], tA1 = (int)rA[1], tB0 = (int)rB[0], tB1 = (int)rB[1];
+      int mA = 0, zA = 0, mB = 0, zB = 0;  // (never materialised: the first statement of a chain writes them)
   #pragma unroll
       for (int k = 0; k < KW; k++)
   #pragma unroll
         for (int h = 0; h < 2; h++) {
-          mac32<ARITH>(mA, zA, as[k][h], az[PL == 2 ? k : 0][h], rA + 2 + 2 * WPL * k, h);
-          mac32<ARITH>(mB, zB, as[k][h], az[PL == 2 ? k : 0][h], rB + 2 + 2 * WPL * k, h);
+          const uint32_t s_ = as[k][h], z_ = az[PL == 2 ? k : 0][h];
+          if (k == 0 && h == 0) {
+            mac32<ARITH, true>(mA, zA, s_, z_, rA + 2 + 2 * WPL * k, h, t, -tA0);
+            mac32<ARITH, true>(mB, zB, s_, z_, rB + 2 + 2 * WPL * k, h, t, -tB0);
+          } else {
+            mac32<ARITH>(mA, zA, s_, z_, rA + 2 + 2 * WPL * k, h, t);
+            mac32<ARITH>(mB, zB, s_, z_, rB + 2 + 2 * WPL * k, h, t);
+          }
         }
       if constexpr (TWO) {
         if (rA[2 + 6 * KW] | rB[2 + 6 * KW]) {  // weights of -2 in one of the two rows (fault injection only)
@@ -798,13 +928,12 @@ __global__ __launch_bounds__(kBlock) void k_vec(const uint64_t *__restrict__ in,
             }
         }
       }
-      const int tA0 = (int)rA[0], tA1 = (int)rA[1], tB0 = (int)rB[0], tB1 = (int)rB[1];
-      if constexpr (ARITH == AR_XNOR) {
-        decide<OUT2>(b0, b1, mA - tA0, tA0 - tA1);
-        decide<OUT2>(b0, b1, mB - tB0, tB0 - tB1);
+      if constexpr (ARITH == AR_XNOR) {  // seeded with -t0: the chain's end is the decision value
+        decide<OUT2>(b0, b1, mA, tA0 - tA1);
+        decide<OUT2>(b0, b1, mB, tB0 - tB1);
       } else {
-        decide<OUT2>(b0, b1, q_of<ARITH>(mA, zA, nn) + tA0, tA1 - tA0);
-        decide<OUT2>(b0, b1, q_of<ARITH>(mB, zB, nn) + tB0, tB1 - tB0);
+        decide<OUT2>(b0, b1, tA0 - d_of<ARITH>(mA, ARITH == AR_TB ? nn : zA), tA1 - tA0);
+        decide<OUT2>(b0, b1, tB0 - d_of<ARITH>(mB, ARITH == AR_TB ? nn : zB), tB1 - tB0);
       }
     }
     if constexpr (POOL) {  // max-pool of a thresholded map = OR of each threshold's fire bits over the quad
@@ -1302,6 +1431,123 @@ __global__ __launch_bounds__(1024) void k_lfc_fused(const uint8_t *__restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------
+// lfcW1A1, mid-size batches (BASELINE config 2: 10 000 MNIST images): the whole network in ONE launch at the
+// throughput kernels' instruction rate.  Six staged launches cost ~5 us each in gaps, prologues and tails --
+// at 10 000 images that is a third of the run (profiles/r02_lfc_block.txt).  Here a 1024-thread block (one per
+// CU, 4 waves per SIMD) owns `ipb` = ceil(n / 256) images and walks the four layers over ALL of them before it
+// moves on: thread = neuron, its weight row sits in VGPRs for the whole layer (the next layer's row is
+// requested before the current one is evaluated), an image's 16 activation words are LDS broadcasts, the
+// wave's 64 decisions are one v_cmp mask = one word of the next layer's input.  Four __syncthreads() per launch
+// whatever the batch.  Per (image, neuron) the VALU issues the same 2 * KW (v_xor, v_bcnt, s_nop) pairs as
+// k_vec_x -- the operands come from VGPR + LDS instead of SGPR + VGPR -- plus ~8 instructions per image and wave
+// for the ballot.
+// ---------------------------------------------------------------------------
+extern __shared__ uint64_t lfc_lds[];  // k_lfc_block: two activation maps [ipb][16] words
+__device__ __forceinline__ void vpop(int &acc, uint32_t w, uint32_t a, uint32_t &t) {
+  asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "+v"(t), "+v"(acc) : "v"(w), "v"(a));
+}
+__device__ __forceinline__ int vpop_seed(uint32_t w, uint32_t a, int seed, uint32_t &t) {
+  int acc;
+  asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %4" : "+v"(t), "=v"(acc) : "v"(w), "v"(a), "v"(seed));
+  return acc;
+}
+template <int KW>
+__device__ __forceinline__ void lfc_row_regs(const uint32_t *__restrict__ rows, int n, uint32_t (&wl)[KW], uint32_t (&wh)[KW], int &nt) {
+  constexpr int ROW_DW = 2 + 2 * KW;
+  const uint32_t *__restrict__ r = rows + (size_t)n * ROW_DW;
+  nt = -(int)r[0];
+  const uint2 *__restrict__ p = reinterpret_cast<const uint2 *>(r + 2);
+#pragma unroll
+  for (int k = 0; k < KW; k++) {
+    const uint2 v = p[k];
+    wl[k] = v.x;
+    wh[k] = v.y;
+  }
+}
+// m - t of this thread's neuron for one image (act: its KW input words in LDS, the same address in every lane).
+// Two chains (low / high dwords), the first seeded with -t.
+template <int KW>
+__device__ __forceinline__ int lfc_neuron(const uint32_t (&wl)[KW], const uint32_t (&wh)[KW], int nt, const uint64_t *act, uint32_t &t) {
+#ifdef BNN_LFC_BLOCK_NOLDS
+  act = lfc_lds;  // timing experiment only: loop-invariant address, the reads leave the image loop
+#endif
+  uint32_t al[KW], ah[KW];
+#pragma unroll
+  for (int k = 0; k + 1 < KW; k += 2) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(act + k);  // ds_read_b128: two words
+    al[k] = v.x; ah[k] = v.y; al[k + 1] = v.z; ah[k + 1] = v.w;
+  }
+  if constexpr (KW & 1) {
+    const uint2 v = *reinterpret_cast<const uint2 *>(act + KW - 1);
+    al[KW - 1] = v.x; ah[KW - 1] = v.y;
+  }
+  int m0 = vpop_seed(wl[0], al[0], nt, t), m1 = vpop_seed(wh[0], ah[0], 0, t);
+#pragma unroll
+  for (int k = 1; k < KW; k++) {
+    vpop(m0, wl[k], al[k], t);
+    vpop(m1, wh[k], ah[k], t);
+  }
+  return m0 + m1;
+}
+
+__global__ __launch_bounds__(1024) void k_lfc_block(const uint8_t *__restrict__ imgs, uint64_t *__restrict__ words,
+                                                     int32_t *__restrict__ classes, const uint32_t *__restrict__ r0,
+                                                     const uint32_t *__restrict__ r1, const uint32_t *__restrict__ r2,
+                                                     const uint32_t *__restrict__ r3, int n_images, int number_class, int ipb) {
+  uint64_t *A = lfc_lds, *B = lfc_lds + (size_t)ipb * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, img0 = blockIdx.x * ipb;
+  const int cnt = min(ipb, n_images - img0);  // block-uniform, >= 1 by the grid size
+  uint32_t t = chain_temp();
+  uint32_t w0l[13], w0h[13], wal[16], wah[16], wbl[16], wbh[16];
+  int nt0, nta, ntb;
+  lfc_row_regs<13>(r0, tid, w0l, w0h, nt0);
+  // binarizeAndPack into A: one lane per output word (words 13..15 of an image are never read by layer 0)
+  for (int idx = tid; idx < cnt * 16; idx += 1024) {
+    const int i = idx >> 4, k = idx & 15;
+    uint64_t word = 0;
+    if (k < 13) {
+      const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(imgs + (size_t)(img0 + i) * 784 + k * 64);
+      const int nq = (k == 12) ? 1 : 4;  // word 12 holds pixels 768..783 only
+      for (int q = 0; q < nq; q++) {
+        const uint4 v = src[q];
+        const uint32_t bits = msb4(v.x) | (msb4(v.y) << 4) | (msb4(v.z) << 8) | (msb4(v.w) << 12);
+        word |= (uint64_t)bits << (16 * q);
+      }
+    }
+    A[idx] = word;
+  }
+  lfc_row_regs<16>(r1, tid, wal, wah, nta);
+  __syncthreads();
+  for (int i = 0; i < cnt; i++) {  // layer 0: A -> B
+    const uint64_t word = __ballot(lfc_neuron<13>(w0l, w0h, nt0, A + i * 16, t) < 0);
+    if (lane == 0) B[i * 16 + wave] = word;
+  }
+  lfc_row_regs<16>(r2, tid, wbl, wbh, ntb);
+  __syncthreads();
+  for (int i = 0; i < cnt; i++) {  // layer 1: B -> A
+    const uint64_t word = __ballot(lfc_neuron<16>(wal, wah, nta, B + i * 16, t) < 0);
+    if (lane == 0) A[i * 16 + wave] = word;
+  }
+  lfc_row_regs<16>(r3, lane, wal, wah, nta);  // layer 3 has 64 neurons: every wave holds all of them (neuron = lane)
+  __syncthreads();
+  for (int i = 0; i < cnt; i++) {  // layer 2: A -> B
+    const uint64_t word = __ballot(lfc_neuron<16>(wbl, wbh, ntb, A + i * 16, t) < 0);
+    if (lane == 0) B[i * 16 + wave] = word;
+  }
+  __syncthreads();
+  for (int i = wave; i < cnt; i += 16) {  // layer 3 + decode: the waves share out the images
+    const uint64_t word = __ballot(lfc_neuron<16>(wal, wah, nta, B + i * 16, t) < 0);
+    if (lane == 0) {
+      words[img0 + i] = word;
+      if (classes) {
+        const uint64_t w = word & (~0ull >> (64 - number_class));
+        classes[img0 + i] = w ? 63 - __builtin_clzll(w) : 0;
+      }
+    }
+  }
+}
+
 // LFC output decode, batched form (testPrebinarized_nolabel_multiple_images,
 // foldedmv-offload.cpp:202-220): mask to number_class bits, class = index of
 // the highest set bit, 0 when none.  (unsigned)log2((double)w) equals that
@@ -1313,6 +1559,17 @@ __global__ __launch_bounds__(kBlock) void k_lfc_decode(const uint64_t *__restric
   const uint64_t mask = ~0ull >> (64 - number_class);
   const uint64_t w = words[i] & mask;
   classes[i] = w ? 63 - __builtin_clzll(w) : 0;
+}
+
+// images: up to here lfcW1A1 runs as one k_lfc_block launch (LDS holds 2 x 128 B per image and block: 256
+// blocks x 576 images); BNN_MI355X_LFC_BLOCK_MAX overrides (tools/batch_sweep.py)
+inline long long lfc_block_max() {
+  static const long long v = [] {
+    const char *e = std::getenv("BNN_MI355X_LFC_BLOCK_MAX");
+    const long long x = e ? std::atoll(e) : 32768;
+    return x > 256 * 576 ? 256LL * 576 : x;
+  }();
+  return v;
 }
 
 // neuron groups per block: all of them once the work items alone fill the chip (256 CUs x 8 blocks),
@@ -1373,7 +1630,11 @@ void run_cnv_t(const CnvLaunch &a) {
     // per block): four times the lanes, a quarter of the serial work of each
     const bool pix = n <= kPixelLaneMax;
     if (a.last_stage >= 1) {
-      if (pix) BNN_LAUNCH((k_vec_x<9, true, 1, 30, 8, true>), grid_for(n * 784, 8), s, A64, B, a.rows[1], (int)(n * 784), 8, 1);
+      if (a.l1_mfma) {  // side experiment (BNN_MI355X_L1=mfma): the layer on the matrix pipe
+        const long long pairs = (n + 1) / 2;
+        hipLaunchKernelGGL(k_l1_mfma, dim3((unsigned)(pairs < 512 ? pairs : 512)), dim3(256), 0, s, reinterpret_cast<const uint32_t *>(a.buf0), B,
+                           a.l1_mfma, (int)n);
+      } else if (pix) BNN_LAUNCH((k_vec_x<9, true, 1, 30, 8, true>), grid_for(n * 784, 8), s, A64, B, a.rows[1], (int)(n * 784), 8, 1);
       else BNN_STAGE((k_quad_x<1, 30, true>), (k_quad_x<1, 30, true, 8>), n * 196, 2, A64, B, a.rows[1]);
     }
     BNN_MARK(a.events, 2, s);
@@ -1474,6 +1735,32 @@ void lfc_workspace_bytes(int abits, size_t *buf0, size_t *buf1) {
   *buf1 = 128 * (size_t)abits;
 }
 
+void l1_mfma_table(const uint32_t *rows, uint8_t *dst) {
+  constexpr int ROW_DW = 2 + 2 * 9;  // cnvW1A1 layer 1: t0, t1, 9 x u64 (bit = 1 <=> weight +1)
+  for (int tap = 0; tap < 9; tap++)
+    for (int mt = 0; mt < 2; mt++)
+      for (int lane = 0; lane < 64; lane++) {
+        const int r = lane & 31, h = lane >> 5, n = 32 * mt + r;
+        const uint32_t bits = rows[n * ROW_DW + 2 + 2 * tap + h];  // channels 32h .. 32h+31 of this tap
+        uint8_t *o = dst + ((size_t)(tap * 2 + mt) * 64 + lane) * 16;
+        for (int j = 0; j < 16; j++) {
+          const uint32_t lo = (bits >> (2 * j)) & 1, hi = (bits >> (2 * j + 1)) & 1;
+          o[j] = (uint8_t)((lo ? 0x2 : 0xA) | ((hi ? 0x2 : 0xA) << 4));
+        }
+      }
+  float *seeds = reinterpret_cast<float *>(dst + kL1MfmaWeights);
+  for (int mt = 0; mt < 2; mt++)
+    for (int h = 0; h < 2; h++)
+      for (int reg = 0; reg < 16; reg++) {
+        const int n = 32 * mt + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        // fire <=> mismatches < t <=> (576 - dot) / 2 < t <=> dot > 576 - 2t =: theta.  dot and theta are even, so
+        // fire <=> dot - theta - 1 > 0; the clamp keeps never / always firing rows inside the exact f32 range
+        long long t = (int)rows[n * ROW_DW];
+        t = t < -1 ? -1 : (t > 578 ? 578 : t);
+        seeds[(mt * 2 + h) * 16 + reg] = (float)(-(576 - 2 * t) - 1);
+      }
+}
+
 hipError_t run_cnv(NetId net, const CnvLaunch &a) {
   if (a.n <= 0) return hipSuccess;
   switch (net) {
@@ -1517,6 +1804,17 @@ hipError_t run_lfc(NetId net, const LfcLaunch &a) {
     }
 #undef BNN_FUSED
     return hipGetLastError();
+  }
+  if (net == NET_LFCW1A1 && n <= lfc_block_max() && !a.events && a.last_stage >= kLfcStages - 1) {
+    // mid-size batch: one block per CU walks all four layers over its share of the images (k_lfc_block)
+    const int ipb = (int)((n + 255) / 256);
+    const size_t lds = (size_t)ipb * 16 * 8 * 2;
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lfc_block), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    if (attr_ok || lds <= 64 * 1024) {
+      hipLaunchKernelGGL(k_lfc_block, dim3((unsigned)((n + ipb - 1) / ipb)), dim3(1024), lds, s, a.images, a.words, a.classes, a.rows[0],
+                         a.rows[1], a.rows[2], a.rows[3], (int)n, a.number_class, ipb);
+      return hipGetLastError();
+    }
   }
   BNN_MARK(a.events, 0, s);
   if (a.last_stage >= 0) BNN_LAUNCH(k_lfc_binarize, grid_for(n * 13, 1), s, a.images, A64, (int)(n * 13));

@@ -65,6 +65,8 @@ struct Runtime {
   std::vector<Fault> last_faults;
   const uint32_t *rows[9] = {};
   const uint8_t *l0_mfma = nullptr;  // layer 0 as an MFMA operand (CNV nets), unless BNN_MI355X_L0=valu
+  uint8_t *d_l1_mfma = nullptr;      // cnvW1A1, BNN_MI355X_L1=mfma only: layer 1 as FP4 MFMA operands (side experiment)
+  bool l1_mfma = false;
   int two_rows = 0;  // rows holding a weight of -2 (2-bit-weight net under fault injection): kernels.hip, two_extra
   // workspace
   int cap = 0;
@@ -168,6 +170,15 @@ int upload_blob() {
   const char *l0 = std::getenv("BNN_MI355X_L0");
   const bool valu = l0 && std::strcmp(l0, "valu") == 0;
   r.l0_mfma = (h->l0_mfma_offset && !valu) ? static_cast<const uint8_t *>(r.d_blob) + h->l0_mfma_offset : nullptr;
+  // side experiment, never the default: layer 1 of cnvW1A1 on the matrix pipe (kernels.hip, k_l1_mfma)
+  const char *l1 = std::getenv("BNN_MI355X_L1");
+  r.l1_mfma = r.spec.id == NET_CNVW1A1 && l1 && std::strcmp(l1, "mfma") == 0;
+  if (r.l1_mfma) {
+    std::vector<uint8_t> tab(kL1MfmaBytes);
+    l1_mfma_table(reinterpret_cast<const uint32_t *>(r.blob.data() + h->layer[1].offset), tab.data());
+    if (!r.d_l1_mfma) HIP_OK(hipMalloc(reinterpret_cast<void **>(&r.d_l1_mfma), kL1MfmaBytes));
+    HIP_OK(hipMemcpy(r.d_l1_mfma, tab.data(), kL1MfmaBytes, hipMemcpyHostToDevice));
+  }
   return 0;
 }
 
@@ -281,6 +292,7 @@ int enqueue(const uint8_t *d_imgs, int n, int ncls, int32_t *d_classes, int16_t 
     a.images = d_imgs; a.n = n; a.buf0 = r.buf0; a.buf1 = r.buf1;
     for (int l = 0; l < 9; l++) a.rows[l] = r.rows[l];
     a.l0_mfma = r.l0_mfma;
+    a.l1_mfma = r.l1_mfma ? r.d_l1_mfma : nullptr;
     a.has_two = r.two_rows > 0;
     a.scores = d_scores; a.classes = d_classes; a.number_class = ncls; a.stream = s; a.events = evs;
     a.last_stage = r.debug_last_stage >= 0 ? r.debug_last_stage : kCnvStages - 1;
@@ -727,6 +739,10 @@ int *inference_multiple_with_faults(const char *path, int number_class, int *ima
   if (!ready()) return nullptr;
   if (r.raw.empty()) {
     fail("fault injection needs the parameter files (load_parameters), not an imported blob");
+    return nullptr;
+  }
+  if (r.l1_mfma) {
+    fail("fault injection is not wired to the BNN_MI355X_L1=mfma experiment (its layer-1 table is not patched)");
     return nullptr;
   }
   ImageFile f;

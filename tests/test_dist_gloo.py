@@ -34,7 +34,12 @@ def _worker(rank, world, port, n_images, ret):
         from bnn import multigpu as mg
         lib = gl.load("lfcW1A1")
         pdir = gl.param_dir("mnist", "lfcW1A1")
+        calls = []
+        real_broadcast = dist.broadcast
+        dist.broadcast = lambda *a, **k: (calls.append(a[0].numel()), real_broadcast(*a, **k))[1]
         blob = mg.distribute_params(lib, pdir, upload=False)          # the one collective of the job
+        dist.broadcast = real_broadcast
+        assert calls == [lib.bnn_mi355x_params_bytes()]               # ONE broadcast, of exactly the blob (no size exchange)
         assert (blob == gl.pack_params("lfcW1A1", pdir)).all()        # every rank holds rank 0's bytes
         imgs = np.random.default_rng(0).integers(0, 256, (n_images, 784), dtype=np.uint8)
         lo, hi = mg.shard_bounds(n_images, world)[rank]

@@ -80,3 +80,35 @@ def test_every_stage_with_weights_of_minus_two(tmp_path):
     assert all((w == -2).any() for w in W)
     check_all_stages("cnvW2A2", str(tmp_path), 43)
     gl.load("cnvW2A2").load_parameters(gl.param_dir("cifar10", "cnvW2A2").encode())
+
+
+def test_layer1_matrix_pipe_experiment_is_bit_exact(tmp_path):
+    """BNN_MI355X_L1=mfma (side experiment): cnvW1A1 layer 1 as an FP4 implicit GEMM on the matrix
+    cores.  Same bits as the XNOR-popcount kernel: the stage's HBM output against the faithful scalar restatement,
+    shipped and random parameters (incl. never / always firing thresholds), odd and even image counts, and the
+    whole network's raw scores on a batch that spans several blocks."""
+    import os
+    import subprocess
+    import sys
+
+    import random_params
+    random_params.make(str(tmp_path), "cnvW1A1", 23)
+    code = (
+        "import sys, numpy as np; sys.path[:0] = [%r, %r]\n"
+        "import torch, gpu_lib as gl, oracle_lib as ol\n"
+        "from test_gpu_layers import stage_output, unpack\n"
+        "L = gl.load('cnvW1A1')\n"
+        "for pdir in (gl.param_dir('cifar10', 'cnvW1A1'), %r):\n"
+        "    L.load_parameters(pdir.encode()); assert L.bnn_mi355x_last_error() == b''\n"
+        "    o = ol.Oracle('cnvW1A1', pdir)\n"
+        "    for n in (1, 2, 5):\n"
+        "        imgs = np.random.default_rng(60 + n).integers(0, 256, (n, 3072), dtype=np.uint8)\n"
+        "        raw = stage_output(L, imgs, 1)\n"
+        "        for i in range(n):\n"
+        "            assert (unpack(raw[i], 196, 64, 1) == o.layer_ref(imgs[i], 1)).all(), (pdir, n, i)\n"
+        "    imgs = np.random.default_rng(8).integers(0, 256, (3001, 3072), dtype=np.uint8)\n"
+        "    net = gl.Net.__new__(gl.Net); net.L, net.network, net.is_cnv, net.isz = L, 'cnvW1A1', True, 3072\n"
+        "    assert (net.raw(imgs) == o.scores_fast(imgs)).all(), pdir\n"
+        "print('mfma-l1-ok')\n" % (os.path.join(gl.ROOT, "tests"), os.path.join(gl.ROOT, "bnn-pynq_amd"), str(tmp_path)))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BNN_MI355X_L1="mfma"), capture_output=True, text=True, timeout=900)
+    assert "mfma-l1-ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
