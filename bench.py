@@ -181,10 +181,15 @@ def main():
     else:
         # rank 0 reads + repacks the files; the ~210 KB blob goes to the other GPUs over RCCL/xGMI:
         # the one collective of the whole job
+        # (= mg.distribute_params, taken apart here to time the collective on its own)
+        blob = mg.pack_params(L, pdir) if rank == 0 else None       # host only: read + repack the reference's files
         dist.barrier()
         tb = time.perf_counter()
-        mg.distribute_params(L, pdir, device=None if a.rehearse_gloo else dev)
+        buf = mg.broadcast_blob(L, blob, 0, None if a.rehearse_gloo else dev)
+        if not a.rehearse_gloo:
+            torch.cuda.synchronize()
         broadcast_ms = (time.perf_counter() - tb) * 1e3
+        mg.import_blob(L, buf)                                       # straight from HBM (RCCL) / from host memory (gloo)
 
     # ---- synthetic batch, resident in HBM before the timed region starts
     g = torch.Generator(device=dev)
@@ -376,6 +381,34 @@ def main():
             out["first_layer_on_integer_pipe"] = {"value": round(5 * a.batch / (time.perf_counter() - t1), 1), "unit": "images/s",
                                                   "note": "BNN_MI355X_L0=valu: no MFMA anywhere (DESIGN.md 5, 'Layer 0 on the matrix pipe')"}
             del os.environ["BNN_MI355X_L0"]
+            # (c) pricing the north-star's "no MFMA" rule on the layer that takes 46 % of the time: cnvW1A1 layer 1 as an
+            # FP4 implicit GEMM on the matrix cores (k_l1_mfma, bit-exact, NOT the product path), everything else as in `value`
+            if a.network == "cnvW1A1":
+                os.environ["BNN_MI355X_L1"] = "mfma"
+                L.bnn_mi355x_import_params(blob.ctypes.data, size)
+                for _ in range(2):
+                    step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    step()
+                torch.cuda.synchronize()
+                rate = 5 * a.batch / (time.perf_counter() - t1)
+                L.bnn_mi355x_profile(1)
+                step()
+                torch.cuda.synchronize()
+                sm = (C.c_float * 16)()
+                nc = C.c_int(0)
+                L.bnn_mi355x_profile_read(sm, 16, C.byref(nc))
+                L.bnn_mi355x_profile(0)
+                import oracle_lib as ol
+                k = 2048
+                same = bool((classes[:k].cpu().numpy() == ol.Oracle(a.network, ol.param_dir(dataset, a.network)).classes_batched(
+                    imgs[:k].cpu().numpy(), ncls, host_cores())).all())
+                out["matrix_pipe_l1"] = {"value": round(rate, 1), "unit": "images/s", "layer1_ms": round(float(sm[1]), 4),
+                                         "layer1_ms_xnor_popcount": round(per_stage[1], 4), "classes_equal_oracle": same,
+                                         "note": "BNN_MI355X_L1=mfma: side figure only, the headline stays on XNOR + popcount (DESIGN.md 5, 'Pricing the rule')"}
+                del os.environ["BNN_MI355X_L1"]
             L.bnn_mi355x_import_params(blob.ctypes.data, size)
             step()
             torch.cuda.synchronize()

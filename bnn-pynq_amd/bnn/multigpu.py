@@ -59,21 +59,26 @@ def distribute_params(lib, param_dir, device=None, group=None, upload=True):
     rank receives the blob in one broadcast over the process group and (upload=True) hands it to its own
     library instance -- straight from HBM when the group's tensors live there (RCCL), from host memory
     otherwise (gloo).  Returns the blob as a numpy array (host copy; the GPU path makes it on demand)."""
-    import torch
     import torch.distributed as dist
     rank = dist.get_rank(group)
     blob = pack_params(lib, param_dir) if rank == 0 else None
     buf = broadcast_blob(lib, blob, 0, device, group)
     if upload:
-        if buf.is_cuda:
-            stream = torch.cuda.current_stream(buf.device).cuda_stream
-            rc = lib.bnn_mi355x_import_params_device(buf.data_ptr(), buf.numel(), stream)
-        else:
-            host = buf.numpy()
-            rc = lib.bnn_mi355x_import_params(host.ctypes.data, host.size)
-        if rc != 0:
-            raise RuntimeError(lib.bnn_mi355x_last_error().decode())
+        import_blob(lib, buf)
     return buf.cpu().numpy()
+
+
+def import_blob(lib, buf):
+    """hand a received blob (uint8 torch tensor, on the GPU or on the host) to this rank's library instance"""
+    import torch
+    if buf.is_cuda:
+        stream = torch.cuda.current_stream(buf.device).cuda_stream
+        rc = lib.bnn_mi355x_import_params_device(buf.data_ptr(), buf.numel(), stream)
+    else:
+        host = buf.numpy()
+        rc = lib.bnn_mi355x_import_params(host.ctypes.data, host.size)
+    if rc != 0:
+        raise RuntimeError(lib.bnn_mi355x_last_error().decode())
 
 
 def gather_classes(local_classes, n_total, group=None):

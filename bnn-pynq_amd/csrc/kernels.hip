@@ -1466,7 +1466,8 @@ __device__ __forceinline__ void lfc_row_regs(const uint32_t *__restrict__ rows, 
   }
 }
 // m - t of this thread's neuron for one image (act: its KW input words in LDS, the same address in every lane).
-// Two chains (low / high dwords), the first seeded with -t.
+// One chain seeded with -t: with four waves sharing the SIMD, consecutive pairs of a wave are ~25 cycles apart,
+// far beyond v_bcnt's latency, so a second chain would only cost the add that joins them.
 template <int KW>
 __device__ __forceinline__ int lfc_neuron(const uint32_t (&wl)[KW], const uint32_t (&wh)[KW], int nt, const uint64_t *act, uint32_t &t) {
 #ifdef BNN_LFC_BLOCK_NOLDS
@@ -1482,14 +1483,40 @@ __device__ __forceinline__ int lfc_neuron(const uint32_t (&wl)[KW], const uint32
     const uint2 v = *reinterpret_cast<const uint2 *>(act + KW - 1);
     al[KW - 1] = v.x; ah[KW - 1] = v.y;
   }
-  int m0 = vpop_seed(wl[0], al[0], nt, t), m1 = vpop_seed(wh[0], ah[0], 0, t);
+  int m = vpop_seed(wl[0], al[0], nt, t);
+  vpop(m, wh[0], ah[0], t);
 #pragma unroll
   for (int k = 1; k < KW; k++) {
-    vpop(m0, wl[k], al[k], t);
-    vpop(m1, wh[k], ah[k], t);
+    vpop(m, wl[k], al[k], t);
+    vpop(m, wh[k], ah[k], t);
   }
-  return m0 + m1;
+  return m;
 }
+
+// One layer of the block's `cnt` images: in -> out (LDS maps [image][16] words).  The 64 decisions of a wave
+// for image i are the v_cmp mask; instead of one lane storing it per image (exec juggling, a branch and an LDS
+// write per image) the mask is parked in lane (i mod 64) of a VGPR pair by two v_writelane, and every 64
+// images -- or at the end -- each lane stores the word of "its" image.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"  // m0 is named as a clobber on purpose (nothing else in this kernel uses it)
+template <int KW>
+__device__ __forceinline__ void lfc_block_layer(const uint32_t (&wl)[KW], const uint32_t (&wh)[KW], int nt, const uint64_t *in,
+                                                uint64_t *out, int cnt, int wave, int lane, uint32_t &t) {
+  for (int base = 0; base < cnt; base += 64) {
+    const int m = __builtin_amdgcn_readfirstlane(min(64, cnt - base));
+    int lo = 0, hi = 0;
+    for (int i = 0; i < m; i++) {
+      const uint64_t word = __ballot(lfc_neuron<KW>(wl, wh, nt, in + (size_t)(base + i) * 16, t) < 0);
+      // (lane select through M0: gfx9 allows one SGPR per VALU instruction besides it)
+      asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+          : "+v"(lo), "+v"(hi)
+          : "s"((uint32_t)word), "s"((uint32_t)(word >> 32)), "s"(i)
+          : "m0");
+    }
+    if (lane < m) out[(size_t)(base + lane) * 16 + wave] = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+  }
+}
+#pragma clang diagnostic pop
 
 __global__ __launch_bounds__(1024) void k_lfc_block(const uint8_t *__restrict__ imgs, uint64_t *__restrict__ words,
                                                      int32_t *__restrict__ classes, const uint32_t *__restrict__ r0,
@@ -1497,7 +1524,7 @@ __global__ __launch_bounds__(1024) void k_lfc_block(const uint8_t *__restrict__ 
                                                      const uint32_t *__restrict__ r3, int n_images, int number_class, int ipb) {
   uint64_t *A = lfc_lds, *B = lfc_lds + (size_t)ipb * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, img0 = blockIdx.x * ipb;
-  const int cnt = min(ipb, n_images - img0);  // block-uniform, >= 1 by the grid size
+  const int cnt = __builtin_amdgcn_readfirstlane(min(ipb, n_images - img0));  // block-uniform (kept in an SGPR), >= 1 by the grid size
   uint32_t t = chain_temp();
   uint32_t w0l[13], w0h[13], wal[16], wah[16], wbl[16], wbh[16];
   int nt0, nta, ntb;
@@ -1519,22 +1546,13 @@ __global__ __launch_bounds__(1024) void k_lfc_block(const uint8_t *__restrict__ 
   }
   lfc_row_regs<16>(r1, tid, wal, wah, nta);
   __syncthreads();
-  for (int i = 0; i < cnt; i++) {  // layer 0: A -> B
-    const uint64_t word = __ballot(lfc_neuron<13>(w0l, w0h, nt0, A + i * 16, t) < 0);
-    if (lane == 0) B[i * 16 + wave] = word;
-  }
+  lfc_block_layer<13>(w0l, w0h, nt0, A, B, cnt, wave, lane, t);  // layer 0: A -> B
   lfc_row_regs<16>(r2, tid, wbl, wbh, ntb);
   __syncthreads();
-  for (int i = 0; i < cnt; i++) {  // layer 1: B -> A
-    const uint64_t word = __ballot(lfc_neuron<16>(wal, wah, nta, B + i * 16, t) < 0);
-    if (lane == 0) A[i * 16 + wave] = word;
-  }
+  lfc_block_layer<16>(wal, wah, nta, B, A, cnt, wave, lane, t);  // layer 1: B -> A
   lfc_row_regs<16>(r3, lane, wal, wah, nta);  // layer 3 has 64 neurons: every wave holds all of them (neuron = lane)
   __syncthreads();
-  for (int i = 0; i < cnt; i++) {  // layer 2: A -> B
-    const uint64_t word = __ballot(lfc_neuron<16>(wbl, wbh, ntb, A + i * 16, t) < 0);
-    if (lane == 0) B[i * 16 + wave] = word;
-  }
+  lfc_block_layer<16>(wbl, wbh, ntb, A, B, cnt, wave, lane, t);  // layer 2: A -> B
   __syncthreads();
   for (int i = wave; i < cnt; i += 16) {  // layer 3 + decode: the waves share out the images
     const uint64_t word = __ballot(lfc_neuron<16>(wal, wah, nta, B + i * 16, t) < 0);
@@ -1561,12 +1579,14 @@ __global__ __launch_bounds__(kBlock) void k_lfc_decode(const uint64_t *__restric
   classes[i] = w ? 63 - __builtin_clzll(w) : 0;
 }
 
-// images: up to here lfcW1A1 runs as one k_lfc_block launch (LDS holds 2 x 128 B per image and block: 256
-// blocks x 576 images); BNN_MI355X_LFC_BLOCK_MAX overrides (tools/batch_sweep.py)
+// images: up to here lfcW1A1 runs as one k_lfc_block launch; measured against the staged path
+// (profiles/r02_lfc_block_sweep.txt): 4 097 images 36 vs 58 us, 6 000 47 vs 58, 10 000 68 vs 75, 16 384 101 vs 100,
+// beyond that the staged kernels win (8 waves per SIMD instead of 4).  LDS would hold 256 blocks x 576 images;
+// BNN_MI355X_LFC_BLOCK_MAX overrides the limit (tools/batch_sweep.py)
 inline long long lfc_block_max() {
   static const long long v = [] {
     const char *e = std::getenv("BNN_MI355X_LFC_BLOCK_MAX");
-    const long long x = e ? std::atoll(e) : 32768;
+    const long long x = e ? std::atoll(e) : 12288;
     return x > 256 * 576 ? 256LL * 576 : x;
   }();
   return v;
