@@ -36,6 +36,7 @@
 #include <stdint.h>
 
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "kernels.h"
@@ -1434,24 +1435,22 @@ __global__ __launch_bounds__(1024) void k_lfc_fused(const uint8_t *__restrict__ 
 // ---------------------------------------------------------------------------
 // lfcW1A1, mid-size batches (BASELINE config 2: 10 000 MNIST images): the whole network in ONE launch at the
 // throughput kernels' instruction rate.  Six staged launches cost ~5 us each in gaps, prologues and tails --
-// at 10 000 images that is a third of the run (profiles/r02_lfc_block.txt).  Here a 1024-thread block (one per
-// CU, 4 waves per SIMD) owns `ipb` = ceil(n / 256) images and walks the four layers over ALL of them before it
-// moves on: thread = neuron, its weight row sits in VGPRs for the whole layer (the next layer's row is
-// requested before the current one is evaluated), an image's 16 activation words are LDS broadcasts, the
-// wave's 64 decisions are one v_cmp mask = one word of the next layer's input.  Four __syncthreads() per launch
-// whatever the batch.  Per (image, neuron) the VALU issues the same 2 * KW (v_xor, v_bcnt, s_nop) pairs as
-// k_vec_x -- the operands come from VGPR + LDS instead of SGPR + VGPR -- plus ~8 instructions per image and wave
-// for the ballot.
+// at 10 000 images that is a third of the run.  A 1024-thread block owns ceil(n / 512) images and walks the
+// four layers over ALL of them before it moves on: thread = neuron, its weight row sits in VGPRs for the whole
+// layer, the wave's 64 decisions for an image are one v_cmp mask = one word of the next layer's input, parked
+// in lane (i mod 64) of a VGPR pair by two v_writelane and stored once per 64 images.  Four hand-offs per
+// launch whatever the batch.
+// First form (round 2, replaced): the image's 16 words broadcast from LDS into 32 VGPRs of every lane -- 128 KB
+// of LDS reads per image and layer per CU, and the counters said that is what the waves waited for
+// (profiles/r02_sq_lfc_block.json: SQ_WAIT_ANY 48 % of wave-cycles, 3.9 SIMD-cycles per VALU instruction against
+// 3.1 in the throughput kernels; 65 us for 10 000 images).  This form keeps a wave-uniform operand where it
+// belongs, in SGPRs: the maps between the layers live in the two global workspace buffers (128 B per image,
+// L2-resident), a layer's output is stored with vector stores, and after the block's barrier + s_dcache_inv
+// the next layer reads it with two s_load_dwordx16 per image through the scalar cache: the pair becomes
+// v_xor(s, v) + v_bcnt exactly as in the throughput kernels, no LDS at all, 47 VGPRs and 68 SGPRs => two
+// 1024-thread blocks per CU (8 waves per SIMD), each covering the other's barriers, weight loads and
+// scalar-load latencies (profiles/r02_lfc_block_sweep.txt: 10 000 images 74 -> 61 us).
 // ---------------------------------------------------------------------------
-extern __shared__ uint64_t lfc_lds[];  // k_lfc_block: two activation maps [ipb][16] words
-__device__ __forceinline__ void vpop(int &acc, uint32_t w, uint32_t a, uint32_t &t) {
-  asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "+v"(t), "+v"(acc) : "v"(w), "v"(a));
-}
-__device__ __forceinline__ int vpop_seed(uint32_t w, uint32_t a, int seed, uint32_t &t) {
-  int acc;
-  asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %4" : "+v"(t), "=v"(acc) : "v"(w), "v"(a), "v"(seed));
-  return acc;
-}
 template <int KW>
 __device__ __forceinline__ void lfc_row_regs(const uint32_t *__restrict__ rows, int n, uint32_t (&wl)[KW], uint32_t (&wh)[KW], int &nt) {
   constexpr int ROW_DW = 2 + 2 * KW;
@@ -1465,70 +1464,97 @@ __device__ __forceinline__ void lfc_row_regs(const uint32_t *__restrict__ rows, 
     wh[k] = v.y;
   }
 }
-// m - t of this thread's neuron for one image (act: its KW input words in LDS, the same address in every lane).
-// One chain seeded with -t: with four waves sharing the SIMD, consecutive pairs of a wave are ~25 cycles apart,
-// far beyond v_bcnt's latency, so a second chain would only cost the add that joins them.
+typedef uint32_t v16u __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void sload_image(const uint64_t *p, v16u &lo, v16u &hi) {  // p: wave-uniform
+  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=s"(lo), "=s"(hi) : "s"(p));
+}
+// (the loads' results must not be used before the wait: the in/out operands make every later use depend on it)
+__device__ __forceinline__ void swait_image(v16u &lo, v16u &hi) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lo), "+s"(hi)); }
+// Scalar-cache prefetch: touch both 64-byte lines of a later image so that its real load hits.  The two
+// destination registers are dummies, but they stay "live" until the wait that retires these loads (swait_prefetch):
+// the compiler must not hand them to anything else while the loads are in flight.
+__device__ __forceinline__ void sprefetch_image(const uint64_t *p, uint32_t &d0, uint32_t &d1) {
+  asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %2, 0x40" : "=s"(d0), "=s"(d1) : "s"(p));
+}
+__device__ __forceinline__ void swait_image(v16u &lo, v16u &hi, uint32_t &d0, uint32_t &d1) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lo), "+s"(hi), "+s"(d0), "+s"(d1));
+}
+
+// m - t of this thread's neuron for one image (its 32 dwords in SGPRs).  (Two neurons per thread -- 4 * KW
+// pairs per scalar-load wait, 512-thread blocks -- was measured too: 3 % faster at 131 072 images, 10 % slower at
+// 10 000, where this kernel is used.)
 template <int KW>
-__device__ __forceinline__ int lfc_neuron(const uint32_t (&wl)[KW], const uint32_t (&wh)[KW], int nt, const uint64_t *act, uint32_t &t) {
-#ifdef BNN_LFC_BLOCK_NOLDS
-  act = lfc_lds;  // timing experiment only: loop-invariant address, the reads leave the image loop
-#endif
-  uint32_t al[KW], ah[KW];
-#pragma unroll
-  for (int k = 0; k + 1 < KW; k += 2) {
-    const uint4 v = *reinterpret_cast<const uint4 *>(act + k);  // ds_read_b128: two words
-    al[k] = v.x; ah[k] = v.y; al[k + 1] = v.z; ah[k + 1] = v.w;
-  }
-  if constexpr (KW & 1) {
-    const uint2 v = *reinterpret_cast<const uint2 *>(act + KW - 1);
-    al[KW - 1] = v.x; ah[KW - 1] = v.y;
-  }
-  int m = vpop_seed(wl[0], al[0], nt, t);
-  vpop(m, wh[0], ah[0], t);
+__device__ __forceinline__ int lfc_neuron_s(const uint32_t (&wl)[KW], const uint32_t (&wh)[KW], int nt, const v16u &lo, const v16u &hi,
+                                            uint32_t &t) {
+  auto word = [&](int d) { return d < 16 ? lo[d] : hi[d - 16]; };
+  int m;
+  asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %4" : "+v"(t), "=v"(m) : "s"(word(0)), "v"(wl[0]), "v"(nt));
+  asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "+v"(t), "+v"(m) : "s"(word(1)), "v"(wh[0]));
 #pragma unroll
   for (int k = 1; k < KW; k++) {
-    vpop(m, wl[k], al[k], t);
-    vpop(m, wh[k], ah[k], t);
+    asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "+v"(t), "+v"(m) : "s"(word(2 * k)), "v"(wl[k]));
+    asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "+v"(t), "+v"(m) : "s"(word(2 * k + 1)), "v"(wh[k]));
   }
   return m;
 }
 
-// One layer of the block's `cnt` images: in -> out (LDS maps [image][16] words).  The 64 decisions of a wave
-// for image i are the v_cmp mask; instead of one lane storing it per image (exec juggling, a branch and an LDS
-// write per image) the mask is parked in lane (i mod 64) of a VGPR pair by two v_writelane, and every 64
-// images -- or at the end -- each lane stores the word of "its" image.
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"  // m0 is named as a clobber on purpose (nothing else in this kernel uses it)
-template <int KW>
-__device__ __forceinline__ void lfc_block_layer(const uint32_t (&wl)[KW], const uint32_t (&wh)[KW], int nt, const uint64_t *in,
-                                                uint64_t *out, int cnt, int wave, int lane, uint32_t &t) {
-  for (int base = 0; base < cnt; base += 64) {
-    const int m = __builtin_amdgcn_readfirstlane(min(64, cnt - base));
-    int lo = 0, hi = 0;
-    for (int i = 0; i < m; i++) {
-      const uint64_t word = __ballot(lfc_neuron<KW>(wl, wh, nt, in + (size_t)(base + i) * 16, t) < 0);
-      // (lane select through M0: gfx9 allows one SGPR per VALU instruction besides it)
-      asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
-          : "+v"(lo), "+v"(hi)
-          : "s"((uint32_t)word), "s"((uint32_t)(word >> 32)), "s"(i)
-          : "m0");
-    }
-    if (lane < m) out[(size_t)(base + lane) * 16 + wave] = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
-  }
+// decisions of this wave's 64 neurons for image i of the chunk -> lane i of (lo, hi)
+__device__ __forceinline__ void park_word(int &lo, int &hi, uint64_t word, int i) {
+  asm("s_mov_b32 m0, %4\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+      : "+v"(lo), "+v"(hi)
+      : "s"((uint32_t)word), "s"((uint32_t)(word >> 32)), "s"(i)
+      : "m0");
 }
 #pragma clang diagnostic pop
 
-__global__ __launch_bounds__(1024) void k_lfc_block(const uint8_t *__restrict__ imgs, uint64_t *__restrict__ words,
-                                                     int32_t *__restrict__ classes, const uint32_t *__restrict__ r0,
-                                                     const uint32_t *__restrict__ r1, const uint32_t *__restrict__ r2,
-                                                     const uint32_t *__restrict__ r3, int n_images, int number_class, int ipb) {
-  uint64_t *A = lfc_lds, *B = lfc_lds + (size_t)ipb * 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, img0 = blockIdx.x * ipb;
-  const int cnt = __builtin_amdgcn_readfirstlane(min(ipb, n_images - img0));  // block-uniform (kept in an SGPR), >= 1 by the grid size
+// one layer over the block's cnt images: in / out = global maps [image][16] words (in: wave-uniform pointer)
+template <int KW>
+__device__ __forceinline__ void lfc_block_layer_s(const uint32_t *__restrict__ rows, int neuron, const uint64_t *in, uint64_t *out, int cnt,
+                                                  int wave, int lane, uint32_t &t) {
+  uint32_t wl[KW], wh[KW];
+  int nt;
+  lfc_row_regs<KW>(rows, neuron, wl, wh, nt);
+  v16u a_lo, a_hi;
+  uint32_t pf0 = 0, pf1 = 0;
+  for (int base = 0; base < cnt; base += 64) {
+    const int m = __builtin_amdgcn_readfirstlane(min(64, cnt - base));
+    int lo = 0, hi = 0;
+    // One image in flight per wave: a second SGPR buffer would push the kernel past 80 SGPRs and cost the second
+    // block per CU; with 8 waves on the SIMD the other seven cover this wave's scalar load.  Every trip also
+    // touches image i + 2 in the scalar cache (the slack behind the workspace covers the two images past the end).
+    for (int i = 0; i < m; i++) {
+      const uint64_t *p = in + (size_t)(base + i) * 16;
+      sload_image(p, a_lo, a_hi);
+      swait_image(a_lo, a_hi, pf0, pf1);
+      sprefetch_image(p + 32, pf0, pf1);
+      park_word(lo, hi, __ballot(lfc_neuron_s<KW>(wl, wh, nt, a_lo, a_hi, t) < 0), i);
+    }
+    if (lane < m) out[(size_t)(base + lane) * 16 + wave] = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+  }
+  swait_image(a_lo, a_hi, pf0, pf1);  // the last prefetches are retired before their registers are given up
+}
+
+// all waves' stores of a layer are in L2, and no stale line of the map is left in the scalar cache
+__device__ __forceinline__ void lfc_block_handoff() {
+  // this wave's stores have reached L2 (the vector L1 writes through; the scalar cache reads from L2, not from
+  // the vector L1 -- __syncthreads() alone orders only what the CU's vector L1 serves)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+__global__ __launch_bounds__(1024, 2) void k_lfc_block_s(const uint8_t *__restrict__ imgs, uint64_t *__restrict__ words,
+                                                          int32_t *__restrict__ classes, uint64_t *__restrict__ gA, uint64_t *__restrict__ gB,
+                                                          const uint32_t *__restrict__ r0, const uint32_t *__restrict__ r1,
+                                                          const uint32_t *__restrict__ r2, const uint32_t *__restrict__ r3, int n_images,
+                                                          int number_class, int ipb) {
+  const int tid = threadIdx.x, lane = tid & 63, img0 = blockIdx.x * ipb;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                  // in an SGPR: it indexes scalar loads
+  const int cnt = __builtin_amdgcn_readfirstlane(min(ipb, n_images - img0));  // block-uniform, >= 1 by the grid size
+  uint64_t *A = gA + (size_t)img0 * 16, *B = gB + (size_t)img0 * 16;
   uint32_t t = chain_temp();
-  uint32_t w0l[13], w0h[13], wal[16], wah[16], wbl[16], wbh[16];
-  int nt0, nta, ntb;
-  lfc_row_regs<13>(r0, tid, w0l, w0h, nt0);
   // binarizeAndPack into A: one lane per output word (words 13..15 of an image are never read by layer 0)
   for (int idx = tid; idx < cnt * 16; idx += 1024) {
     const int i = idx >> 4, k = idx & 15;
@@ -1544,23 +1570,28 @@ __global__ __launch_bounds__(1024) void k_lfc_block(const uint8_t *__restrict__ 
     }
     A[idx] = word;
   }
-  lfc_row_regs<16>(r1, tid, wal, wah, nta);
-  __syncthreads();
-  lfc_block_layer<13>(w0l, w0h, nt0, A, B, cnt, wave, lane, t);  // layer 0: A -> B
-  lfc_row_regs<16>(r2, tid, wbl, wbh, ntb);
-  __syncthreads();
-  lfc_block_layer<16>(wal, wah, nta, B, A, cnt, wave, lane, t);  // layer 1: B -> A
-  lfc_row_regs<16>(r3, lane, wal, wah, nta);  // layer 3 has 64 neurons: every wave holds all of them (neuron = lane)
-  __syncthreads();
-  lfc_block_layer<16>(wbl, wbh, ntb, A, B, cnt, wave, lane, t);  // layer 2: A -> B
-  __syncthreads();
-  for (int i = wave; i < cnt; i += 16) {  // layer 3 + decode: the waves share out the images
-    const uint64_t word = __ballot(lfc_neuron<16>(wal, wah, nta, B + i * 16, t) < 0);
-    if (lane == 0) {
-      words[img0 + i] = word;
-      if (classes) {
-        const uint64_t w = word & (~0ull >> (64 - number_class));
-        classes[img0 + i] = w ? 63 - __builtin_clzll(w) : 0;
+  lfc_block_handoff();
+  lfc_block_layer_s<13>(r0, tid, A, B, cnt, wave, lane, t);
+  lfc_block_handoff();
+  lfc_block_layer_s<16>(r1, tid, B, A, cnt, wave, lane, t);
+  lfc_block_handoff();
+  lfc_block_layer_s<16>(r2, tid, A, B, cnt, wave, lane, t);
+  lfc_block_handoff();
+  {  // layer 3 (64 neurons: neuron = lane in every wave) + decode: the waves share out the images
+    uint32_t wl[16], wh[16];
+    int nt;
+    lfc_row_regs<16>(r3, lane, wl, wh, nt);
+    v16u lo, hi;
+    for (int i = wave; i < cnt; i += 16) {
+      sload_image(B + (size_t)i * 16, lo, hi);
+      swait_image(lo, hi);
+      const uint64_t word = __ballot(lfc_neuron_s<16>(wl, wh, nt, lo, hi, t) < 0);
+      if (lane == 0) {
+        words[img0 + i] = word;
+        if (classes) {
+          const uint64_t w = word & (~0ull >> (64 - number_class));
+          classes[img0 + i] = w ? 63 - __builtin_clzll(w) : 0;
+        }
       }
     }
   }
@@ -1579,15 +1610,14 @@ __global__ __launch_bounds__(kBlock) void k_lfc_decode(const uint64_t *__restric
   classes[i] = w ? 63 - __builtin_clzll(w) : 0;
 }
 
-// images: up to here lfcW1A1 runs as one k_lfc_block launch; measured against the staged path
-// (profiles/r02_lfc_block_sweep.txt): 4 097 images 36 vs 58 us, 6 000 47 vs 58, 10 000 68 vs 75, 16 384 101 vs 100,
-// beyond that the staged kernels win (8 waves per SIMD instead of 4).  LDS would hold 256 blocks x 576 images;
-// BNN_MI355X_LFC_BLOCK_MAX overrides the limit (tools/batch_sweep.py)
+// images: up to here lfcW1A1 runs as one k_lfc_block_s launch; measured against the staged path
+// (profiles/r02_lfc_block_sweep.txt, us per batch): 4 097 images 35 vs 58, 6 000 42 vs 58, 10 000 61 vs 74,
+// 16 384 88 vs 96, 24 576 122 vs 129, 32 768 161 vs 163, 65 536 310 vs 304: beyond ~40 000 the staged kernels win
+// (64 pairs per scalar-load wait instead of 32).  BNN_MI355X_LFC_BLOCK_MAX overrides (tools/batch_sweep.py).
 inline long long lfc_block_max() {
   static const long long v = [] {
     const char *e = std::getenv("BNN_MI355X_LFC_BLOCK_MAX");
-    const long long x = e ? std::atoll(e) : 12288;
-    return x > 256 * 576 ? 256LL * 576 : x;
+    return e ? std::atoll(e) : 32768LL;
   }();
   return v;
 }
@@ -1826,15 +1856,11 @@ hipError_t run_lfc(NetId net, const LfcLaunch &a) {
     return hipGetLastError();
   }
   if (net == NET_LFCW1A1 && n <= lfc_block_max() && !a.events && a.last_stage >= kLfcStages - 1) {
-    // mid-size batch: one block per CU walks all four layers over its share of the images (k_lfc_block)
-    const int ipb = (int)((n + 255) / 256);
-    const size_t lds = (size_t)ipb * 16 * 8 * 2;
-    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lfc_block), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
-    if (attr_ok || lds <= 64 * 1024) {
-      hipLaunchKernelGGL(k_lfc_block, dim3((unsigned)((n + ipb - 1) / ipb)), dim3(1024), lds, s, a.images, a.words, a.classes, a.rows[0],
-                         a.rows[1], a.rows[2], a.rows[3], (int)n, a.number_class, ipb);
-      return hipGetLastError();
-    }
+    // mid-size batch: two 1024-thread blocks per CU, each walking all four layers over its share of the images
+    const int ipb = (int)((n + 511) / 512);
+    hipLaunchKernelGGL(k_lfc_block_s, dim3((unsigned)((n + ipb - 1) / ipb)), dim3(1024), 0, s, a.images, a.words, a.classes, A64, B64, a.rows[0],
+                       a.rows[1], a.rows[2], a.rows[3], (int)n, a.number_class, ipb);
+    return hipGetLastError();
   }
   BNN_MARK(a.events, 0, s);
   if (a.last_stage >= 0) BNN_LAUNCH(k_lfc_binarize, grid_for(n * 13, 1), s, a.images, A64, (int)(n * 13));

@@ -574,10 +574,10 @@ def test_device_calls_on_two_streams_share_the_workspace_safely():
 
 @pytest.mark.parametrize("n", [4097, 4351, 4352, 5000, 10000, 16383, 32768, 32769, 70000])
 def test_lfc_mid_batches_take_the_block_kernel(n):
-    """lfcW1A1 between the one-launch small-batch kernel (<= 4096 images) and the staged throughput path: one
-    k_lfc_block launch, a 1024-thread block per ceil(n / 256) images walking all four layers (BASELINE config 2
-    is 10 000 images).  Sizes either side of the policy edges, ragged last blocks (4351 = 17 * 255 + 16 ...),
-    raw words through the host path and classes through the device path."""
+    """lfcW1A1 between the one-launch small-batch kernel (<= 4096 images) and the staged throughput path (> 32 768):
+    one k_lfc_block_s launch, a 1024-thread block per ceil(n / 512) images walking all four layers with the
+    activations fed through SGPRs (BASELINE config 2 is 10 000 images).  Sizes either side of the policy edges,
+    ragged last blocks, raw words through the host path and classes through the device path."""
     import torch
     net = gpu_net("lfcW1A1", "mnist")
     o = oracle("lfcW1A1", "mnist")
@@ -592,3 +592,25 @@ def test_lfc_mid_batches_take_the_block_kernel(n):
     torch.cuda.synchronize()
     assert (words.cpu().numpy().view(np.uint64) == want).all()
     assert cls.cpu().numpy().tolist() == o.classes_batched(imgs, 10).tolist()
+
+
+def test_lfc_block_kernel_beyond_its_policy_range():
+    """k_lfc_block_s with more than 64 images per block (several chunks of 64 per layer, ragged last chunk and last
+    block), which the shipped policy never asks of it: forced with BNN_MI355X_LFC_BLOCK_MAX"""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np; sys.path[:0] = [%r, %r]\n"
+        "import torch, gpu_lib as gl, oracle_lib as ol\n"
+        "net = gl.Net('lfcW1A1', 'mnist'); o = ol.Oracle('lfcW1A1', ol.param_dir('mnist', 'lfcW1A1'))\n"
+        "for n in (32769, 70001, 131072):\n"      # through the device entry point: the host path feeds chunks of 32 768
+        "    imgs = np.random.default_rng(n).integers(0, 256, (n, 784), dtype=np.uint8)\n"
+        "    d = torch.from_numpy(imgs).cuda(); w = torch.zeros(n, dtype=torch.int64, device='cuda'); c = torch.zeros(n, dtype=torch.int32, device='cuda')\n"
+        "    torch.cuda.synchronize()\n"
+        "    assert net.L.bnn_mi355x_inference_device(d.data_ptr(), n, 10, c.data_ptr(), None, w.data_ptr(), None) == 0\n"
+        "    torch.cuda.synchronize()\n"
+        "    assert (w.cpu().numpy().view(np.uint64) == o.words_fast(imgs)).all(), n\n"
+        "    assert (c.cpu().numpy() == o.classes_batched(imgs, 10)).all(), n\n"
+        "print('block-ok')\n" % (os.path.join(gl.ROOT, "tests"), os.path.join(gl.ROOT, "bnn-pynq_amd")))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BNN_MI355X_LFC_BLOCK_MAX="1000000"), capture_output=True, text=True, timeout=600)
+    assert "block-ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
