@@ -420,6 +420,9 @@ def main():
             "lfcW1A1_10000": measure_config("lfcW1A1", "mnist", 10000, dev, local_rank, 300, 20),
             "lfcW1A1_131072": measure_config("lfcW1A1", "mnist", 131072, dev, local_rank, 40, 5),
             "cnvW2A2_131072": measure_config("cnvW2A2", "cifar10", 131072, dev, local_rank, 8, 2),
+            # the two W1A2 overlays, same entry point
+            "cnvW1A2_131072": measure_config("cnvW1A2", "cifar10", 131072, dev, local_rank, 8, 2),
+            "lfcW1A2_131072": measure_config("lfcW1A2", "mnist", 131072, dev, local_rank, 40, 5),
         }
         if not all(v.get("classes_equal_oracle") for v in out["other_configs"].values()):
             print(json.dumps(out))

@@ -1470,16 +1470,6 @@ __device__ __forceinline__ void sload_image(const uint64_t *p, v16u &lo, v16u &h
 }
 // (the loads' results must not be used before the wait: the in/out operands make every later use depend on it)
 __device__ __forceinline__ void swait_image(v16u &lo, v16u &hi) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lo), "+s"(hi)); }
-// Scalar-cache prefetch: touch both 64-byte lines of a later image so that its real load hits.  The two
-// destination registers are dummies, but they stay "live" until the wait that retires these loads (swait_prefetch):
-// the compiler must not hand them to anything else while the loads are in flight.
-__device__ __forceinline__ void sprefetch_image(const uint64_t *p, uint32_t &d0, uint32_t &d1) {
-  asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %2, 0x40" : "=s"(d0), "=s"(d1) : "s"(p));
-}
-__device__ __forceinline__ void swait_image(v16u &lo, v16u &hi, uint32_t &d0, uint32_t &d1) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lo), "+s"(hi), "+s"(d0), "+s"(d1));
-}
-
 // m - t of this thread's neuron for one image (its 32 dwords in SGPRs).  (Two neurons per thread -- 4 * KW
 // pairs per scalar-load wait, 512-thread blocks -- was measured too: 3 % faster at 131 072 images, 10 % slower at
 // 10 000, where this kernel is used.)
@@ -1517,23 +1507,20 @@ __device__ __forceinline__ void lfc_block_layer_s(const uint32_t *__restrict__ r
   int nt;
   lfc_row_regs<KW>(rows, neuron, wl, wh, nt);
   v16u a_lo, a_hi;
-  uint32_t pf0 = 0, pf1 = 0;
   for (int base = 0; base < cnt; base += 64) {
     const int m = __builtin_amdgcn_readfirstlane(min(64, cnt - base));
     int lo = 0, hi = 0;
     // One image in flight per wave: a second SGPR buffer would push the kernel past 80 SGPRs and cost the second
-    // block per CU; with 8 waves on the SIMD the other seven cover this wave's scalar load.  Every trip also
-    // touches image i + 2 in the scalar cache (the slack behind the workspace covers the two images past the end).
+    // block per CU; with 8 waves on the SIMD the other seven cover this wave's scalar load.  (Touching image i + 2
+    // in the scalar cache ahead of time was measured: no gain -- and it would have been the only access outside
+    // the block's own images.)
     for (int i = 0; i < m; i++) {
-      const uint64_t *p = in + (size_t)(base + i) * 16;
-      sload_image(p, a_lo, a_hi);
-      swait_image(a_lo, a_hi, pf0, pf1);
-      sprefetch_image(p + 32, pf0, pf1);
+      sload_image(in + (size_t)(base + i) * 16, a_lo, a_hi);
+      swait_image(a_lo, a_hi);
       park_word(lo, hi, __ballot(lfc_neuron_s<KW>(wl, wh, nt, a_lo, a_hi, t) < 0), i);
     }
     if (lane < m) out[(size_t)(base + lane) * 16 + wave] = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
   }
-  swait_image(a_lo, a_hi, pf0, pf1);  // the last prefetches are retired before their registers are given up
 }
 
 // all waves' stores of a layer are in L2, and no stale line of the map is left in the scalar cache

@@ -291,6 +291,24 @@ def test_lfc_small_batches_take_the_fused_kernel(network, n):
         assert cls.cpu().numpy().tolist() == o.classes_batched(imgs, 10).tolist()
 
 
+def test_lfc_device_decode_refuses_label_sets_it_cannot_decode_exactly():
+    """the device-side LFC decode is an exact floor(log2); the reference's (unsigned) log2((double) word) rounds up
+    for some words of 48 and more bits (e.g. 2^49 - 1): beyond 47 classes the device entry point refuses classes
+    (words are still available) instead of returning a decode that could differ"""
+    import torch
+    net = gpu_net("lfcW1A1", "mnist")
+    d = torch.zeros((4, 784), dtype=torch.uint8, device="cuda")
+    cls = torch.zeros(4, dtype=torch.int32, device="cuda")
+    words = torch.zeros(4, dtype=torch.int64, device="cuda")
+    assert net.L.bnn_mi355x_inference_device(d.data_ptr(), 4, 48, cls.data_ptr(), None, None, None) != 0
+    assert b"number_class <= 47" in net.L.bnn_mi355x_last_error()
+    assert net.L.bnn_mi355x_inference_device(d.data_ptr(), 4, 48, None, None, words.data_ptr(), None) == 0
+    assert net.L.bnn_mi355x_inference_device(d.data_ptr(), 4, 47, cls.data_ptr(), None, None, None) == 0
+    torch.cuda.synchronize()
+    o = oracle("lfcW1A1", "mnist")
+    assert (words.cpu().numpy().view(np.uint64) == o.words_fast(np.zeros((4, 784), np.uint8))).all()
+
+
 def test_lfc_device_decode():
     import torch
     net = gpu_net("lfcW1A1", "mnist")

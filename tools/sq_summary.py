@@ -26,23 +26,31 @@ def short(name):
 
 
 def load(dirs):
+    """per kernel, only the dispatches at its LARGEST grid: the library's load-time warm-up launches the same kernels
+    on small batches, which must not be averaged into the figures of the measured batch"""
+    rows = collections.defaultdict(list)
+    for d in dirs:
+        for path in glob.glob(d + "/*/*_counter_collection.csv"):
+            for r in csv.DictReader(open(path)):
+                k = short(r["Kernel_Name"])
+                if k:
+                    rows[k].append((path, r))
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     dur = collections.defaultdict(list)
     meta = {}
-    for d in dirs:
-        for path in glob.glob(d + "/*/*_counter_collection.csv"):
-            seen = set()
-            for r in csv.DictReader(open(path)):
-                k = short(r["Kernel_Name"])
-                if not k:
-                    continue
-                acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
-                key = (path, r["Dispatch_Id"])
-                if key not in seen:
-                    seen.add(key)
-                    dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-                    meta[k] = {"grid": int(r["Grid_Size"]), "wg": int(r["Workgroup_Size"]), "vgpr": int(r["VGPR_Count"]),
-                               "sgpr": int(r["SGPR_Count"]), "lds": int(r["LDS_Block_Size"])}
+    for k, lst in rows.items():
+        g = max(int(r["Grid_Size"]) for _, r in lst)
+        seen = set()
+        for path, r in lst:
+            if int(r["Grid_Size"]) != g:
+                continue
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            key = (path, r["Dispatch_Id"])
+            if key not in seen:
+                seen.add(key)
+                dur[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                meta[k] = {"grid": g, "wg": int(r["Workgroup_Size"]), "vgpr_granules": int(r["VGPR_Count"]),
+                           "sgpr": int(r["SGPR_Count"]), "lds": int(r["LDS_Block_Size"])}
     return acc, dur, meta
 
 
