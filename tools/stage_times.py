@@ -3,12 +3,13 @@
 bnn_mi355x_inference_device (profiling on: the staged form at every size), and the wall time per call with
 profiling off (the shipped dispatch policy, launch gaps included)."""
 import ctypes as C
+import os
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, "tests")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import gpu_lib as gl  # noqa: E402
 
 net = sys.argv[1]
