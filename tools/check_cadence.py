@@ -44,6 +44,9 @@ CHECKS = [
     ("k_quad<2, 2, 12, true, true, 32, false>", ("v_bitop3_b32",), 144, 12),
     ("k_quad<3, 1, 30, true, true, 32, false>", ("v_and_b32", "v_bitop3_b32"), 144, 12),
     ("k_vec<2, 16, true, false, 1, 1, 32, false, false>", ("v_bitop3_b32",), 64, 10),
+    # one-launch LFC kernel: per image 2 * 16 pairs (weights in VGPRs, the image in SGPRs), then the ballot (v_cmp)
+    # and two v_writelane
+    ("k_lfc_block_s", ("v_xor_b32",), 32, 4, ("v_cmp",)),
 ]
 FORBIDDEN = ("v_cmp", "v_cndmask", "v_mov_b32")
 SLACK_VALU, SLACK_BUBBLES = 4, 2
@@ -105,7 +108,7 @@ def is_valu(mn):
     return mn.startswith("v_")
 
 
-def check_loop(loop, logic_ops, pairs, other_valu):
+def check_loop(loop, logic_ops, pairs, other_valu, allowed=()):
     problems = []
     n_pairs = 0
     i = 0
@@ -113,7 +116,7 @@ def check_loop(loop, logic_ops, pairs, other_valu):
     direct_valu = long_bubbles = 0
     while i < len(loop):
         mn, ops = loop[i]
-        if any(mn.startswith(f) for f in FORBIDDEN):
+        if any(mn.startswith(f) for f in FORBIDDEN) and not any(mn.startswith(a) for a in allowed):
             problems.append("forbidden instruction in the loop body: %s %s" % (mn, ops))
         if mn == "v_bcnt_u32_b32":
             problems.append("v_bcnt without its logic op directly in front (instruction %d)" % i)
@@ -156,7 +159,7 @@ def check_loop(loop, logic_ops, pairs, other_valu):
 def run(obj):
     fns = functions(disassemble(obj))
     report, ok = {}, True
-    for prefix, logic_ops, pairs, other in CHECKS:
+    for prefix, logic_ops, pairs, other, *rest in CHECKS:
         names = [n for n in fns if ("::" + prefix + "(") in n or n.startswith("void " + prefix + "(") or (prefix + "(") in n]
         if len(names) != 1:
             report[prefix] = {"problems": ["kernel not found in the code object (%d matches)" % len(names)]}
@@ -169,7 +172,7 @@ def run(obj):
             report[prefix] = {"problems": ["no loop found"]}
             ok = False
             continue
-        r = check_loop(loops[0], logic_ops, pairs, other)
+        r = check_loop(loops[0], logic_ops, pairs, other, rest[0] if rest else ())
         report[prefix] = r
         ok = ok and not r["problems"]
     return ok, report
