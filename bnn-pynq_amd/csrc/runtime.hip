@@ -765,6 +765,7 @@ int *inference_multiple_with_faults(const char *path, int number_class, int *ima
     if (reserve(n) || reserve_host(1, (size_t)n)) return -1;
     std::vector<std::vector<uint8_t>> patches;  // row images must outlive their asynchronous upload
     patches.reserve(r.last_faults.size());
+    DrainOnFailure drain;  // (declared after `patches`: a failing return drains the stream before they are released)
     // one pair of events around the whole campaign: the row patches between the runs are a few hundred
     // bytes each, and an event pair per run would cost more than they do
     while (r.time_events.size() < 2) {
@@ -805,11 +806,11 @@ int *inference_multiple_with_faults(const char *path, int number_class, int *ima
     for (int i = 0; !r.spec.is_cnv && i < n; i++) result[i] = lfc_class_batched(w[i], number_class);
     float ms_total = 0.f;
     HIP_OK(hipEventElapsedTime(&ms_total, r.time_events[0], r.time_events[1]));
+    drain.ok();
     return (int)(ms_total * 1000.0 + 0.5);  // device microseconds of the campaign
   };
   const int total_us = run();
   if (total_us < 0) {
-    (void)hipStreamSynchronize(r.stream);  // nothing may still read the patch buffers
     delete[] result;
     return nullptr;
   }
@@ -1011,6 +1012,9 @@ int bnn_mi355x_images_to_cifar(const uint8_t *const *pixels, const int *widths, 
   if (grow(r.d_pp_rec, r.pp_rec_cap, (size_t)n_images * 3073)) return -1;
   // host copies of the coefficient tables must outlive their (asynchronous) upload: kept until the next sync
   std::vector<std::vector<int32_t>> keep;
+  // declared after `keep`, so destroyed (= streams drained on a failing exit) before it: uploads from the caller's
+  // pictures and from `keep` may still be queued when an error returns
+  DrainOnFailure drain;
   int last_w = -1, last_h = -1;
   size_t off_bh = 0, off_kv = 0, off_bv = 0;
   int ksize_h = 0, ksize_v = 0, ow = 0, oh = 0;
@@ -1055,6 +1059,7 @@ int bnn_mi355x_images_to_cifar(const uint8_t *const *pixels, const int *widths, 
   }
   HIP_OK(hipMemcpyAsync(records, r.d_pp_rec, (size_t)n_images * 3073, hipMemcpyDeviceToHost, r.stream));
   HIP_OK(hipStreamSynchronize(r.stream));
+  drain.ok();
   return 0;
 }
 
