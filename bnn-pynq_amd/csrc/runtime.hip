@@ -83,7 +83,8 @@ struct Runtime {
   // before they return; bnn_mi355x_inference_device leaves work in flight on the CALLER's stream, so it marks
   // the end of that work with ws_event and the next call on any other stream waits for it first.
   hipEvent_t ws_event = nullptr;
-  hipStream_t ws_last = nullptr;
+  hipStream_t ws_last = nullptr;  // the caller's stream of that call (may be the null stream: hence the flag)
+  bool ws_pending = false;
   hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
   std::vector<hipEvent_t> time_events;
   // file path: records as they lie on disk, two host chunks (filled by reader threads) and two HBM chunks
@@ -274,9 +275,9 @@ int enqueue(const uint8_t *d_imgs, int n, int ncls, int32_t *d_classes, int16_t 
   Runtime &r = rt();
   hipError_t e;
   hipEvent_t *evs = nullptr;
-  if (r.ws_last && r.ws_last != s) {  // an earlier device-pointer call on another stream may still own the workspace
+  if (r.ws_pending && r.ws_last != s) {  // an earlier device-pointer call on another stream may still own the workspace
     HIP_OK(hipStreamWaitEvent(s, r.ws_event, 0));
-    r.ws_last = nullptr;
+    r.ws_pending = false;
   }
   if (r.profiling) {
     const int need = (r.spec.is_cnv ? kCnvStages : kLfcStages) + 1;
@@ -1125,6 +1126,7 @@ int bnn_mi355x_inference_device(const void *d_images, int n_images, int number_c
     if (cap == hipStreamCaptureStatusNone) {
       HIP_OK(hipEventRecord(r.ws_event, s));
       r.ws_last = s;
+      r.ws_pending = true;
     }
   }
   return 0;

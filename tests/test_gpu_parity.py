@@ -562,13 +562,14 @@ def test_device_calls_on_two_streams_share_the_workspace_safely():
     batches = [rand_images("cnvW1A1", n, 900 + k) for k in range(4)]
     dev = [torch.from_numpy(b).cuda() for b in batches]
     out = [torch.full((n,), -1, dtype=torch.int32, device="cuda") for _ in range(4)]
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    streams = [torch.cuda.Stream().cuda_stream, None, torch.cuda.Stream().cuda_stream]   # None: the null stream
+    keep = streams  # (the Stream objects' handles stay valid while the process lives; torch caches its streams)
     assert L.bnn_mi355x_reserve(n) == 0
     torch.cuda.synchronize()
     for rep in range(3):
         for k in range(4):
-            s = streams[k & 1]
-            assert L.bnn_mi355x_inference_device(dev[k].data_ptr(), n, 10, out[k].data_ptr(), None, None, s.cuda_stream) == 0
+            s = streams[(rep * 4 + k) % 3]
+            assert L.bnn_mi355x_inference_device(dev[k].data_ptr(), n, 10, out[k].data_ptr(), None, None, s) == 0
     torch.cuda.synchronize()
     for k in range(4):
         assert (out[k].cpu().numpy() == o.classes_batched(batches[k], 10)).all(), k
