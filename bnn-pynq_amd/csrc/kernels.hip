@@ -385,7 +385,10 @@ __device__ __forceinline__ uint32_t fp4_pm1(uint32_t byte) {
 __global__ __launch_bounds__(256, 2) void k_l1_mfma(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
                                                      const uint8_t *__restrict__ tab, int n_images) {
   __shared__ uint4 plane[2][2][kL1Pix];  // [image of the pair][h][pixel]
+  __shared__ uint32_t lut[256];          // 8 channel bits -> 8 FP4 nibbles (the expansion is 4 lookups per source dword
+                                         // instead of 4 x 7 integer instructions)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c = lane & 31, h = lane >> 5;
+  lut[tid] = fp4_pm1((uint32_t)tid);
   // weights: 9 taps x 2 neuron tiles, 16 bytes each, for the whole kernel
   const uint4 *__restrict__ wt = reinterpret_cast<const uint4 *>(tab);
   v8i wreg[9][2];
@@ -396,26 +399,42 @@ __global__ __launch_bounds__(256, 2) void k_l1_mfma(const uint32_t *__restrict__
       const uint4 v = wt[(tap * 2 + mt) * 64 + lane];
       wreg[tap][mt] = v8i{(int)v.x, (int)v.y, (int)v.z, (int)v.w, 0, 0, 0, 0};
     }
-  const float *__restrict__ seeds = reinterpret_cast<const float *>(tab + kL1MfmaWeights);
-  v16f seed[2];
-#pragma unroll
-  for (int mt = 0; mt < 2; mt++)
-#pragma unroll
-    for (int i = 0; i < 16; i++) seed[mt][i] = seeds[(mt * 2 + h) * 16 + i];
+  // accumulator seeds -(theta + 1): [neuron tile][h][16] floats, read from LDS at the start of every row pair (32
+  // VGPRs less than keeping them: with the prefetch registers the kernel would spill)
+  __shared__ v16f seed_lds[2][2];
+  if (tid < 64) reinterpret_cast<float *>(seed_lds)[tid] = reinterpret_cast<const float *>(tab + kL1MfmaWeights)[tid];
   const int cc = c < 28 ? c : 27;  // idle lanes repeat column 27 (their results are dropped)
+  // The bit maps of the NEXT pair of images are requested (15 dwords per thread, into registers) before the MFMAs of
+  // the current pair are issued: measured without it the block alternated ~3 us of load latency with ~3.6 us of
+  // matrix work and the matrix pipe sat at 46 % (profiles/r02_sq_l1_matrix_pipe.json).
+  uint32_t pre[15];
+  auto fetch = [&](int pair) {
+    const int img0 = pair * 2, lim = min(2, n_images - img0) * 1800;
+#pragma unroll
+    for (int j = 0; j < 15; j++) {
+      const int d = tid + 256 * j;
+      pre[j] = d < lim ? in[(size_t)img0 * 1800 + d] : 0u;
+    }
+  };
+  if (blockIdx.x * 2 < n_images) fetch(blockIdx.x);
   for (int pair = blockIdx.x; pair * 2 < n_images; pair += gridDim.x) {
     const int img0 = pair * 2, nimg = min(2, n_images - img0);
     __syncthreads();  // the previous pair's planes are no longer read
-    for (int d = tid; d < nimg * 1800; d += 256) {  // one source dword (32 channels of a pixel) per iteration
-      const int i = d / 1800, e = d - i * 1800, pix = e >> 1, hh = e & 1;
-      const uint32_t bits = in[(size_t)(img0 + i) * 1800 + e];
-      plane[i][hh][pix] = make_uint4(fp4_pm1(bits), fp4_pm1(bits >> 8), fp4_pm1(bits >> 16), fp4_pm1(bits >> 24));
+#pragma unroll
+    for (int j = 0; j < 15; j++) {  // one source dword (32 channels of a pixel) per iteration
+      const int d = tid + 256 * j;
+      if (d < nimg * 1800) {
+        const int i = d >= 1800, e = d - i * 1800, pix = e >> 1, hh = e & 1;
+        const uint32_t bits = pre[j];
+        plane[i][hh][pix] = make_uint4(lut[bits & 255], lut[(bits >> 8) & 255], lut[(bits >> 16) & 255], lut[bits >> 24]);
+      }
     }
+    if ((pair + gridDim.x) * 2 < n_images) fetch(pair + gridDim.x);
     __syncthreads();
     for (int rp = wave; rp < nimg * 14; rp += 4) {  // row pair (2r, 2r+1) of image i
       const int i = rp / 14, r = rp - i * 14;
       const uint4 *__restrict__ P = &plane[i][h][0];
-      v16f acc[2][2] = {{seed[0], seed[0]}, {seed[1], seed[1]}};  // [neuron tile][row of the pair]
+      v16f acc[2][2] = {{seed_lds[0][h], seed_lds[0][h]}, {seed_lds[1][h], seed_lds[1][h]}};  // [neuron tile][row of the pair]
 #pragma unroll
       for (int kx = 0; kx < 3; kx++) {
         v8i b[4];  // input rows 2r .. 2r+3 at column c + kx
@@ -436,13 +455,12 @@ __global__ __launch_bounds__(256, 2) void k_l1_mfma(const uint32_t *__restrict__
       uint32_t word[2];
 #pragma unroll
       for (int mt = 0; mt < 2; mt++) {
-        int v0[16], v1[16];
+        // vertical max-pool on the accumulators: both rows' results negative (neither fires) <=> their maximum is
+        // negative -- 16 v_max_f32 (FP pipe) instead of 16 more sign extractions on the integer pipe
+        int v[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-          v0[k] = __float_as_int(acc[mt][0][k]);
-          v1[k] = __float_as_int(acc[mt][1][k]);
-        }
-        const uint32_t nf = or_halves(sign_nibbles(v0, h) & sign_nibbles(v1, h));  // !fire of both rows, 32 neurons
+        for (int k = 0; k < 16; k++) v[k] = __float_as_int(fmaxf(acc[mt][0][k], acc[mt][1][k]));
+        const uint32_t nf = or_halves(sign_nibbles(v, h));  // !fire of the row pair, 32 neurons
         const uint32_t pooled = nf & (uint32_t)__builtin_amdgcn_mov_dpp((int)nf, 0xB1, 0xF, 0xF, true);  // & lane c ^ 1
         word[mt] = ~pooled;
       }
