@@ -129,6 +129,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target length of the CPU baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive and integer-pipe-first-layer side measurements")
+    ap.add_argument("--dist-world1", action="store_true",
+                    help="run the multi-GPU code path (process group, broadcast, gathers, self-check) with a world of ONE rank over "
+                         "the real backend: what a one-GPU box can exercise of the RCCL calls")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="multi-rank dry run on ONE GPU: gloo instead of RCCL, every rank computes on cuda:0 "
                          "(exercises launch/broadcast/shard/timing code where only one GPU is available)")
@@ -156,8 +159,13 @@ def main():
     local_rank %= max(torch.cuda.device_count(), 1)   # a launcher may expose one device per rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or a.dist_world1
+    if use_dist:
         import torch.distributed as dist
+        if a.dist_world1 and "RANK" not in os.environ:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            os.environ.update(RANK="0", WORLD_SIZE="1")
         if a.rehearse_gloo:
             dist.init_process_group("gloo")
         else:
@@ -166,14 +174,14 @@ def main():
     if not os.path.exists(gl.lib_path(a.network)) and rank == 0:
         import subprocess  # a checkout without the built libraries: build them once (hipcc is in the image)
         subprocess.run(["make", "-s", "-j8", "-C", os.path.join(ROOT, "bnn-pynq_amd")], check=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     L = gl.load(a.network)
     assert L.bnn_mi355x_set_device(local_rank) == 0
 
     # ---- parameters: rank 0 packs the reference's param files, everyone else gets the blob over RCCL
     pdir = gl.param_dir(dataset, a.network)
-    if world == 1:
+    if not use_dist:
         L.load_parameters(pdir.encode())
         err = L.bnn_mi355x_last_error().decode()
         if err:
@@ -206,7 +214,7 @@ def main():
             raise RuntimeError(L.bnn_mi355x_last_error().decode())
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -224,7 +232,7 @@ def main():
     nst = L.bnn_mi355x_profile_read(stage_ms, 16, C.byref(nchunks))
     L.bnn_mi355x_profile(0)
     multi = None
-    if world > 1:
+    if use_dist:
         cdev = "cpu" if a.rehearse_gloo else dev
         own_elapsed = elapsed
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
@@ -261,7 +269,7 @@ def main():
                     sys.exit("PARITY FAILURE in the %d-rank run" % world)
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -464,7 +472,7 @@ def main():
         out["cpu_baseline"]["faithful_single_thread"] = {"value": round(k / (time.perf_counter() - t1), 2), "unit": "images/s",
                                                           "cores": 1, "sample": "%d images" % k}
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
