@@ -391,32 +391,36 @@ def main():
             del os.environ["BNN_MI355X_L0"]
             # (c) pricing the north-star's "no MFMA" rule on the layer that takes 46 % of the time: cnvW1A1 layer 1 as an
             # FP4 implicit GEMM on the matrix cores (k_l1_mfma, bit-exact, NOT the product path), everything else as in `value`
+            # (d) the same layer in the north-star's literal wording (k_l1_literal: LDS-staged weight tile, __popcll, shuffle
+            # pooling; untuned): the measured price of fetching weights from SGPRs and pooling inside a lane instead
             if a.network == "cnvW1A1":
-                os.environ["BNN_MI355X_L1"] = "mfma"
-                L.bnn_mi355x_import_params(blob.ctypes.data, size)
-                for _ in range(2):
-                    step()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(5):
-                    step()
-                torch.cuda.synchronize()
-                rate = 5 * a.batch / (time.perf_counter() - t1)
-                L.bnn_mi355x_profile(1)
-                step()
-                torch.cuda.synchronize()
-                sm = (C.c_float * 16)()
-                nc = C.c_int(0)
-                L.bnn_mi355x_profile_read(sm, 16, C.byref(nc))
-                L.bnn_mi355x_profile(0)
                 import oracle_lib as ol
-                k = 2048
-                same = bool((classes[:k].cpu().numpy() == ol.Oracle(a.network, ol.param_dir(dataset, a.network)).classes_batched(
-                    imgs[:k].cpu().numpy(), ncls, host_cores())).all())
-                out["matrix_pipe_l1"] = {"value": round(rate, 1), "unit": "images/s", "layer1_ms": round(float(sm[1]), 4),
-                                         "layer1_ms_xnor_popcount": round(per_stage[1], 4), "classes_equal_oracle": same,
-                                         "note": "BNN_MI355X_L1=mfma: side figure only, the headline stays on XNOR + popcount (DESIGN.md 5, 'Pricing the rule')"}
-                del os.environ["BNN_MI355X_L1"]
+                ref = ol.Oracle(a.network, ol.param_dir(dataset, a.network)).classes_batched(imgs[:2048].cpu().numpy(), ncls, host_cores())
+                for mode, key, note in (
+                        ("mfma", "matrix_pipe_l1", "BNN_MI355X_L1=mfma: side figure only, the headline stays on XNOR + popcount (DESIGN.md 5, 'Pricing the rule')"),
+                        ("lds", "layer1_lds_popcll_shuffle_form", "BNN_MI355X_L1=lds: layer 1 as the north-star words it (weights staged in LDS, __popcll, "
+                                "wavefront-shuffle pooling), untuned; comparison only (DESIGN.md 5, 'Where the product departs from the wording')")):
+                    os.environ["BNN_MI355X_L1"] = mode
+                    L.bnn_mi355x_import_params(blob.ctypes.data, size)
+                    for _ in range(2):
+                        step()
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(5):
+                        step()
+                    torch.cuda.synchronize()
+                    rate = 5 * a.batch / (time.perf_counter() - t1)
+                    L.bnn_mi355x_profile(1)
+                    step()
+                    torch.cuda.synchronize()
+                    sm = (C.c_float * 16)()
+                    nc = C.c_int(0)
+                    L.bnn_mi355x_profile_read(sm, 16, C.byref(nc))
+                    L.bnn_mi355x_profile(0)
+                    out[key] = {"value": round(rate, 1), "unit": "images/s", "layer1_ms": round(float(sm[1]), 4),
+                                "layer1_ms_xnor_popcount": round(per_stage[1], 4),
+                                "classes_equal_oracle": bool((classes[:2048].cpu().numpy() == ref).all()), "note": note}
+                    del os.environ["BNN_MI355X_L1"]
             L.bnn_mi355x_import_params(blob.ctypes.data, size)
             step()
             torch.cuda.synchronize()

@@ -15,6 +15,7 @@ struct CnvLaunch {
   const uint8_t *l0_mfma;     // device, layer-0 MFMA table (packed_params.h); null: integer-pipe k_conv0
   const uint8_t *l1_mfma;     // device, cnvW1A1 layer 1 as FP4 MFMA operands (l1_mfma_table); null: the XNOR-popcount kernel.
                               // Side experiment only (BNN_MI355X_L1=mfma): never the default path.
+  bool l1_literal;            // cnvW1A1, BNN_MI355X_L1=lds: layer 1 in the north-star's literal formulation (comparison figure only)
   bool has_two;               // cnvW2A2: some row holds a weight of -2 (fault injection): the -2-aware kernel variants
   int16_t *scores;            // device, n x 64, may be null
   int32_t *classes;           // device, n, may be null

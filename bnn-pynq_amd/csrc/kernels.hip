@@ -355,6 +355,47 @@ __global__ __launch_bounds__(kBlock) void k_conv0_mfma(const uint8_t *__restrict
 }
 
 // ---------------------------------------------------------------------------
+// COMPARISON FIGURE, not the product path (BNN_MI355X_L1=lds): cnvW1A1 layer 1 written the way the north-star
+// words it -- weight tile staged in LDS with coalesced loads, 64-bit XNOR + __popcll, the threshold as a compare,
+// max-pool as a wavefront-shuffle reduction (lane = output pixel, the four pixels of a pooling quad on four
+// consecutive lanes).  Straightforward code, no instruction-level tuning: it is here so that the bench line can
+// carry the measured price of the two places where the product departs from that wording (weights from SGPRs
+// through the scalar cache instead of LDS; one lane per 2x2 quad with min-before-compare instead of shuffles).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_l1_literal(const uint64_t *__restrict__ in, uint64_t *__restrict__ out,
+                                                        const uint32_t *__restrict__ rows, int n_items) {
+  __shared__ uint64_t w[64][9];
+  __shared__ int thr[64];
+  for (int i = threadIdx.x; i < 64 * 20; i += kBlock) {  // a row = {t0, t1, 9 x u64}
+    const int n = i / 20, j = i - n * 20;
+    const uint32_t v = rows[i];
+    if (j == 0) thr[n] = (int)v;
+    else if (j >= 2) reinterpret_cast<uint32_t *>(&w[n][0])[j - 2] = v;
+  }
+  __syncthreads();
+  const int item = blockIdx.x * kBlock + threadIdx.x;            // (n_items is a multiple of 4: whole quads)
+  const int it = item < n_items ? item : n_items - 1;
+  const int quad = it >> 2, sub = it & 3, img = quad / 196, q = quad - img * 196, qy = q / 14, qx = q - qy * 14;
+  const int oy = 2 * qy + (sub >> 1), ox = 2 * qx + (sub & 1);
+  const uint64_t *__restrict__ base = in + (size_t)img * 900 + (size_t)oy * 30 + ox;
+  uint64_t a[9];
+#pragma unroll
+  for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+    for (int kx = 0; kx < 3; kx++) a[ky * 3 + kx] = base[ky * 30 + kx];
+  uint64_t bits = 0;
+  for (int n = 0; n < 64; n++) {
+    int m = 0;
+#pragma unroll
+    for (int j = 0; j < 9; j++) m += __popcll(w[n][j] ^ a[j]);
+    bits |= (uint64_t)(m < thr[n]) << n;
+  }
+  bits |= __shfl_xor(bits, 1, 64);  // max-pool of a thresholded map = OR over the quad
+  bits |= __shfl_xor(bits, 2, 64);
+  if (sub == 0 && item < n_items) out[quad] = bits;
+}
+
+// ---------------------------------------------------------------------------
 // SIDE EXPERIMENT, not the product path (BNN_MI355X_L1=mfma; DESIGN.md 5 "Pricing the rule"): cnvW1A1 layer 1
 // -- 46 % of the network's time on the integer pipe -- as an implicit GEMM on the matrix cores.  The north-star
 // rules the matrix pipe out for the bitwise layers; this kernel exists to put a measured number next to that
@@ -1685,7 +1726,9 @@ void run_cnv_t(const CnvLaunch &a) {
     // per block): four times the lanes, a quarter of the serial work of each
     const bool pix = n <= kPixelLaneMax;
     if (a.last_stage >= 1) {
-      if (a.l1_mfma) {  // side experiment (BNN_MI355X_L1=mfma): the layer on the matrix pipe
+      if (a.l1_literal) {  // comparison figure (BNN_MI355X_L1=lds): the north-star's wording, untuned
+        BNN_LAUNCH(k_l1_literal, dim3((unsigned)((n * 784 + kBlock - 1) / kBlock)), s, A64, reinterpret_cast<uint64_t *>(B), a.rows[1], (int)(n * 784));
+      } else if (a.l1_mfma) {  // side experiment (BNN_MI355X_L1=mfma): the layer on the matrix pipe
         const long long pairs = (n + 1) / 2;
         hipLaunchKernelGGL(k_l1_mfma, dim3((unsigned)(pairs < 512 ? pairs : 512)), dim3(256), 0, s, reinterpret_cast<const uint32_t *>(a.buf0), B,
                            a.l1_mfma, (int)n);

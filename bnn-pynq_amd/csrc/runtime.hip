@@ -66,7 +66,7 @@ struct Runtime {
   const uint32_t *rows[9] = {};
   const uint8_t *l0_mfma = nullptr;  // layer 0 as an MFMA operand (CNV nets), unless BNN_MI355X_L0=valu
   uint8_t *d_l1_mfma = nullptr;      // cnvW1A1, BNN_MI355X_L1=mfma only: layer 1 as FP4 MFMA operands (side experiment)
-  bool l1_mfma = false;
+  bool l1_mfma = false, l1_literal = false;  // BNN_MI355X_L1=mfma / =lds (comparison figures, never the default)
   int two_rows = 0;  // rows holding a weight of -2 (2-bit-weight net under fault injection): kernels.hip, two_extra
   // workspace
   int cap = 0;
@@ -174,6 +174,7 @@ int upload_blob() {
   // side experiment, never the default: layer 1 of cnvW1A1 on the matrix pipe (kernels.hip, k_l1_mfma)
   const char *l1 = std::getenv("BNN_MI355X_L1");
   r.l1_mfma = r.spec.id == NET_CNVW1A1 && l1 && std::strcmp(l1, "mfma") == 0;
+  r.l1_literal = r.spec.id == NET_CNVW1A1 && l1 && std::strcmp(l1, "lds") == 0;
   if (r.l1_mfma) {
     std::vector<uint8_t> tab(kL1MfmaBytes);
     l1_mfma_table(reinterpret_cast<const uint32_t *>(r.blob.data() + h->layer[1].offset), tab.data());
@@ -294,6 +295,7 @@ int enqueue(const uint8_t *d_imgs, int n, int ncls, int32_t *d_classes, int16_t 
     for (int l = 0; l < 9; l++) a.rows[l] = r.rows[l];
     a.l0_mfma = r.l0_mfma;
     a.l1_mfma = r.l1_mfma ? r.d_l1_mfma : nullptr;
+    a.l1_literal = r.l1_literal;
     a.has_two = r.two_rows > 0;
     a.scores = d_scores; a.classes = d_classes; a.number_class = ncls; a.stream = s; a.events = evs;
     a.last_stage = r.debug_last_stage >= 0 ? r.debug_last_stage : kCnvStages - 1;
@@ -742,8 +744,8 @@ int *inference_multiple_with_faults(const char *path, int number_class, int *ima
     fail("fault injection needs the parameter files (load_parameters), not an imported blob");
     return nullptr;
   }
-  if (r.l1_mfma) {
-    fail("fault injection is not wired to the BNN_MI355X_L1=mfma experiment (its layer-1 table is not patched)");
+  if (r.l1_mfma || r.l1_literal) {
+    fail("fault injection is not wired to the BNN_MI355X_L1 comparison forms (the matrix-pipe table is not patched)");
     return nullptr;
   }
   ImageFile f;

@@ -82,9 +82,11 @@ def test_every_stage_with_weights_of_minus_two(tmp_path):
     gl.load("cnvW2A2").load_parameters(gl.param_dir("cifar10", "cnvW2A2").encode())
 
 
-def test_layer1_matrix_pipe_experiment_is_bit_exact(tmp_path):
+@pytest.mark.parametrize("mode", ["mfma", "lds"])
+def test_layer1_matrix_pipe_experiment_is_bit_exact(tmp_path, mode):
     """BNN_MI355X_L1=mfma (side experiment): cnvW1A1 layer 1 as an FP4 implicit GEMM on the matrix
-    cores.  Same bits as the XNOR-popcount kernel: the stage's HBM output against the faithful scalar restatement,
+    cores; BNN_MI355X_L1=lds (comparison figure): the same layer in the north-star's literal wording (LDS-staged
+    weights, __popcll, shuffle pooling).  Same bits as the XNOR-popcount kernel: the stage's HBM output against the faithful scalar restatement,
     shipped and random parameters (incl. never / always firing thresholds), odd and even image counts, and the
     whole network's raw scores on a batch that spans several blocks."""
     import os
@@ -109,6 +111,6 @@ def test_layer1_matrix_pipe_experiment_is_bit_exact(tmp_path):
         "    imgs = np.random.default_rng(8).integers(0, 256, (3001, 3072), dtype=np.uint8)\n"
         "    net = gl.Net.__new__(gl.Net); net.L, net.network, net.is_cnv, net.isz = L, 'cnvW1A1', True, 3072\n"
         "    assert (net.raw(imgs) == o.scores_fast(imgs)).all(), pdir\n"
-        "print('mfma-l1-ok')\n" % (os.path.join(gl.ROOT, "tests"), os.path.join(gl.ROOT, "bnn-pynq_amd"), str(tmp_path)))
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BNN_MI355X_L1="mfma"), capture_output=True, text=True, timeout=900)
-    assert "mfma-l1-ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+        "print('alt-l1-ok')\n" % (os.path.join(gl.ROOT, "tests"), os.path.join(gl.ROOT, "bnn-pynq_amd"), str(tmp_path)))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BNN_MI355X_L1=mode), capture_output=True, text=True, timeout=900)
+    assert "alt-l1-ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
