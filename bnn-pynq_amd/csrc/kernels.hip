@@ -164,10 +164,10 @@ __device__ __forceinline__ int finish(int m, int z, int nzt) {
 // uint8 p -> int8 q = clamp(floor(256*p/255 - 128 + 0.5)) = p - 128 + (p >= 128) - (p == 255),
 // four bytes at a time (no carry can cross a byte: see DESIGN.md).
 __device__ __forceinline__ uint32_t quantise4(uint32_t p) {
-  const uint32_t t = p ^ 0x80808080u;                         // p - 128 per byte
-  const uint32_t hi = (p >> 7) & 0x01010101u;                 // p >= 128
-  const uint32_t f = (((t & 0x7F7F7F7Fu) + 0x01010101u) >> 7) & hi;  // p == 255
-  return t + (hi ^ f);
+  const uint32_t t = p ^ 0x80808080u;                     // p - 128 per byte
+  const uint32_t s = (t & 0x7F7F7F7Fu) + 0x01010101u;     // bit 7 of a byte: its low seven bits are all ones (p = 127 or 255)
+  const uint32_t inc = p & ~s & 0x80808080u;              // 128 <= p < 255, at bit 7 (one v_bitop3)
+  return t + (inc >> 7);
 }
 
 // bits = (bits << 1) | (v < 0)
@@ -195,7 +195,9 @@ __device__ __forceinline__ void gather_taps(const uint8_t *__restrict__ imgs, in
     for (int r = 0; r < 3; r++) {
       const int off = c * 256 + r * 8;
       const uint32_t d0 = row0[off];
-      const uint32_t d1 = row0[off + 1 <= last ? off + 1 : last];
+      // (only the last dword read of the image's last rows can leave the image: off + 1 <= 529 and the row base is
+      // at most 239, so the clamp is needed for c = r = 2 alone -- the others keep their immediate offsets)
+      const uint32_t d1 = (c == 2 && r == 2) ? row0[off + 1 <= last ? off + 1 : last] : row0[off + 1];
       g[c * 3 + r] = __builtin_amdgcn_alignbyte(d1, d0, sh);
     }
 #pragma unroll
@@ -291,7 +293,7 @@ __device__ __forceinline__ uint32_t or_halves(uint32_t x) {
 }
 
 template <bool OUT2>
-__global__ __launch_bounds__(kBlock) void k_conv0_mfma(const uint8_t *__restrict__ imgs, uint32_t *__restrict__ out,
+__global__ __launch_bounds__(kBlock, 2) void k_conv0_mfma(const uint8_t *__restrict__ imgs, uint32_t *__restrict__ out,
                                                         const uint8_t *__restrict__ l0tab, int n_items) {
   const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
   const int pix = blockIdx.x * kBlock + threadIdx.x;   // lane = output pixel, like k_conv0
