@@ -12,7 +12,7 @@ echo "bench default done"; tail -c 600 $O/bench_default.json; echo
 for n in cnvW1A2 cnvW2A2 lfcW1A1 lfcW1A2; do python3 $R/bench.py --network $n --no-extras 2>/dev/null | tail -1 > $O/bench_$n.json; done
 echo "bench lines done"
 B="python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras"
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- $B > $O/prof_bench.json 2>$O/prof.err
+BNN_MI355X_NO_WARMUP=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- $B > $O/prof_bench.json 2>$O/prof.err  # (without the load-time warm-up, whose small launches of the same kernels would be averaged in)
 echo "kernel trace done"
 B="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $B > $O/pmc_fetch.json 2>$O/pmc_fetch.err
