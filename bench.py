@@ -9,8 +9,9 @@ images are independent, so ranks exchange nothing on the data path: the only
 collective is the one-time RCCL broadcast of the packed parameter blob.
 
     python bench.py                          # 1 GPU, defaults finish in ~1-2 min
+    python bench.py --gpus N --steps K --warmup W      # starts its own N ranks (one fresh process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W      # or under a launcher: same ranks, same line
 
 Everything the timed region runs goes through the product's C ABI
 (include/bnn_mi355x.h).  oracle/ is touched only by the cpu_baseline leg (rank
@@ -25,13 +26,124 @@ import sys
 import time
 
 import numpy as np
-import torch  # before the product library: one HIP runtime per process
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "bnn-pynq_amd"))
-import gpu_lib as gl  # noqa: E402  (ctypes binding of the product C ABI)
-from bnn import multigpu as mg  # noqa: E402  (packed-blob broadcast, shard helpers)
+torch = gl = mg = None  # bound by _rank_imports(): the self-launching parent (below) imports neither torch nor the product
+
+
+def _rank_imports():
+    """torch and the product binding, in a process that is a rank (or the single-GPU run).  torch first: one HIP
+    runtime per process."""
+    global torch, gl, mg
+    import torch as _torch
+    import gpu_lib as _gl                 # ctypes binding of the product C ABI
+    from bnn import multigpu as _mg       # packed-blob broadcast, shard helpers
+    torch, gl, mg = _torch, _gl, _mg
+
+
+METRIC = "images/sec (whole node) CNV-W1A1 CIFAR-10-shape batch"
+
+
+# ---- `python3 bench.py --gpus N` started plainly (no torchrun around it): this process becomes a launcher ----------
+# It makes NO GPU call and imports neither torch nor the product library: it counts the devices in a short-lived
+# child, starts one fresh child process per rank with the environment torch.distributed.run would give it
+# (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT), relays what they print -- rank 0 prints the
+# JSON line -- and exits with the first non-zero return code.  Whatever goes wrong before a rank prints the line, the
+# launcher prints a JSON line itself ({"error": ...}), so a failed N-rank start is a record, not silence.
+def visible_gpus():
+    """number of HIP devices a child process sees (the launcher itself never touches the GPU)"""
+    import subprocess
+    code = "import torch,sys; sys.stdout.write(str(torch.cuda.device_count()))"
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+        return int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else 0
+    except Exception:
+        return 0
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def rank_commands(n, argv, port, python=None, script=None):
+    """[(argv, env-additions)] of the N rank processes: this script again with the same arguments"""
+    python = python or sys.executable
+    script = script or os.path.abspath(__file__)
+    out = []
+    for r in range(n):
+        env = {"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "GROUP_RANK": "0",
+               "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0",
+               "BNN_BENCH_SELF_LAUNCHED": "1"}
+        out.append(([python, "-u", script] + list(argv), env))
+    return out
+
+
+def error_line(a, msg, **extra):
+    d = {"metric": METRIC, "error": msg, "value": None, "unit": "images/s", "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup}
+    d.update(extra)
+    print(json.dumps(d), flush=True)
+
+
+def self_launch(a, argv):
+    import subprocess
+    import threading
+    need = 1 if a.rehearse_gloo else a.gpus
+    have = visible_gpus()
+    if have < need:
+        error_line(a, "bench.py --gpus %d needs %d visible GPU(s), this machine shows %d" % (a.gpus, need, have), n_gpus_visible=have)
+        return 3
+    lib = os.path.join(ROOT, "bnn-pynq_amd", "bnn", "libraries", "mi355x", "python_sw-%s-mi355x.so" % a.network)
+    if not os.path.exists(lib):   # a checkout without the built libraries: build once, before the ranks race for it
+        subprocess.run(["make", "-s", "-j8", "-C", os.path.join(ROOT, "bnn-pynq_amd")], check=True, stdout=sys.stderr)
+    procs, seen_json, lock = [], [False], threading.Lock()
+
+    def relay(rank, pipe):
+        for line in pipe:
+            with lock:
+                if line.startswith("{") and '"metric"' in line:
+                    seen_json[0] = True
+                    sys.stdout.write(line)
+                    sys.stdout.flush()
+                else:               # library prints ("Setting network weights ...") of every rank: keep stdout for the line
+                    sys.stderr.write("[rank %d] %s" % (rank, line))
+    threads = []
+    for r, (cmd, env) in enumerate(rank_commands(a.gpus, argv, free_port())):
+        p = subprocess.Popen(cmd, env=dict(os.environ, **env), stdout=subprocess.PIPE, text=True, bufsize=1)
+        procs.append(p)
+        t = threading.Thread(target=relay, args=(r, p.stdout), daemon=True)
+        t.start()
+        threads.append(t)
+    rc, failed = 0, None
+    live = set(range(a.gpus))
+    deadline = None
+    while live:
+        for r in sorted(live):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            live.discard(r)
+            if c != 0 and rc == 0:
+                rc, failed = c, r
+                deadline = time.time() + 30.0     # the others hang in a collective without their peer: give them 30 s
+        if deadline and time.time() > deadline:
+            for r in live:                        # exactly the processes started above, nothing by pattern
+                procs[r].kill()
+        time.sleep(0.05)
+    for t in threads:
+        t.join(timeout=5)
+    if rc != 0 and not seen_json[0]:
+        error_line(a, "rank %d of %d exited with code %d before the result line was printed" % (failed, a.gpus, rc), returncode=rc)
+    elif rc == 0 and not seen_json[0]:
+        error_line(a, "all %d ranks exited 0 but none printed a result line" % a.gpus)
+        rc = 4
+    return rc
 
 
 def host_cores():
@@ -79,7 +191,8 @@ def measure_config(network, dataset, batch, dev, device_index, steps, warmup, ch
     is_cnv = network.startswith("cnv")
     isz = 3072 if is_cnv else 784
     L = gl.load(network)
-    assert L.bnn_mi355x_set_device(device_index) == 0 or L.bnn_mi355x_last_error()
+    if L.bnn_mi355x_set_device(device_index) != 0:   # (a library already bound to this ordinal answers 0)
+        return {"error": L.bnn_mi355x_last_error().decode()}
     L.load_parameters(gl.param_dir(dataset, network).encode())
     err = L.bnn_mi355x_last_error().decode()
     if err:
@@ -118,7 +231,7 @@ def measure_config(network, dataset, batch, dev, device_index, steps, warmup, ch
             "classes_equal_oracle": same, "checked_images": k}
 
 
-def parse():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -135,25 +248,33 @@ def parse():
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="multi-rank dry run on ONE GPU: gloo instead of RCCL, every rank computes on cuda:0 "
                          "(exercises launch/broadcast/shard/timing code where only one GPU is available)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def main():
-    a = parse()
+    a = parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a, sys.argv[1:]))    # no GPU call, no torch, no product library in this process
+    _rank_imports()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % a.gpus)
-        a.gpus = world
+        a.gpus = world                            # started by a launcher: its world size is the truth
     is_cnv = a.network.startswith("cnv")
     dataset = a.dataset or ("cifar10" if is_cnv else "mnist")
     ncls = 10
     isz = 3072 if is_cnv else 784
 
     if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU: the product has no CPU path")
+        if rank == 0:
+            error_line(a, "bench.py needs a GPU: the product has no CPU path", n_gpus_visible=0)
+        sys.exit(3)
+    if not a.rehearse_gloo and torch.cuda.device_count() < min(world, int(os.environ.get("LOCAL_WORLD_SIZE", world))):
+        if rank == 0:
+            error_line(a, "%d ranks on this node but only %d GPU(s) visible" % (world, torch.cuda.device_count()),
+                       n_gpus_visible=torch.cuda.device_count())
+        sys.exit(3)
     if a.rehearse_gloo:
         local_rank = 0
     local_rank %= max(torch.cuda.device_count(), 1)   # a launcher may expose one device per rank
@@ -326,7 +447,7 @@ def main():
                 "stage_times_source": "HIP events around every stage inside the timed region" if events_in_region else
                 "second pass of the same steps with HIP events (staged form); `value` is timed without them on the shipped dispatch policy, which may be a single launch at this size",
                 "stages_ms": {names[i]: round(per_stage[i], 4) for i in range(nst)}}
-    out = {"metric": "images/sec (whole node) CNV-W1A1 CIFAR-10-shape batch" if a.network == "cnvW1A1"
+    out = {"metric": METRIC if a.network == "cnvW1A1"
            else "images/sec (whole node) %s batch" % a.network,
            "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
            "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",

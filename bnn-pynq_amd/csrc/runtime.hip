@@ -49,7 +49,55 @@ namespace bnn {
 namespace {
 
 constexpr int kMaxChunk = 131072;  // images per pass through the stages
-constexpr int kHostChunk = 32768;  // host-buffer path: H2D of chunk i+1 overlaps the stages of chunk i
+constexpr int kHostChunk = 32768;  // host-buffer / file path: H2D of chunk i+1 overlaps the stages of chunk i (largest chunk)
+constexpr int kHeadChunk = 2048;   // ... the first chunk: what the stages wait for before anything runs
+constexpr int kTailChunk = 4096;   // ... the last chunk: whose stages run after the last byte has arrived
+
+// Chunk boundaries of a host-buffer / file call: base[c] .. base[c+1] are the images of chunk c.
+// The pipeline is copy | stages, double buffered.  With equal chunks the first copy (32 768 CIFAR records =
+// 100 MB: ~3 ms of pread + H2D) runs with the GPU idle and the last chunk's stages (~2.7 ms) run with the link idle.
+// So the chunks ramp: 2048, 4096, ... doubling up to kHostChunk from the front, and 4096, 8192, ... from the back
+// (what is left goes in the middle), and at most ~0.5 ms is exposed at either end.
+// BNN_MI355X_CHUNKS=head:tail:max overrides the three sizes (0 = no ramp at that end; tuning / A-B runs).
+std::vector<int> plan_chunks(int n, bool single) {
+  // (sizes are tuned in bytes on CIFAR records: an MNIST image is a quarter of one)
+  const int scale = net_spec(BNN_NETWORK).is_cnv ? 1 : 4;
+  int head = kHeadChunk * scale, tail = kTailChunk * scale, big = kHostChunk;
+  if (const char *e = std::getenv("BNN_MI355X_CHUNKS")) {
+    int h = 0, t = 0, b = 0;
+    if (std::sscanf(e, "%d:%d:%d", &h, &t, &b) == 3 && b >= 256 && b <= kHostChunk && h >= 0 && t >= 0) { head = h; tail = t; big = b; }
+  }
+  std::vector<int> front, back;
+  int rem = n;
+  if (single || n <= 2 * head) {  // nothing worth overlapping
+    front.push_back(n);
+    rem = 0;
+  }
+  int sf = head > 0 ? head : big, sb = tail > 0 ? tail : big;
+  if (sf > big) sf = big;
+  while (rem > 0) {
+    int t = sf < rem ? sf : rem;
+    front.push_back(t);
+    rem -= t;
+    sf = 2 * sf < big ? 2 * sf : big;
+    if (rem > 0 && sb < big) {
+      t = sb < rem ? sb : rem;
+      back.push_back(t);
+      rem -= t;
+      sb = 2 * sb < big ? 2 * sb : big;
+    }
+  }
+  std::vector<int> base;
+  base.push_back(0);
+  for (int t : front) base.push_back(base.back() + t);
+  for (size_t i = back.size(); i-- > 0;) base.push_back(base.back() + back[i]);
+  return base;
+}
+int largest_chunk(const std::vector<int> &base) {
+  int m = 0;
+  for (size_t c = 0; c + 1 < base.size(); c++) m = base[c + 1] - base[c] > m ? base[c + 1] - base[c] : m;
+  return m;
+}
 
 struct Runtime {
   const NetSpec &spec = net_spec(BNN_NETWORK);
@@ -128,6 +176,7 @@ int bind_device() {
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
     return fail("no HIP device available: this runtime has no CPU fallback");
   if (r.device >= 0) HIP_OK(hipSetDevice(r.device));
+  else HIP_OK(hipGetDevice(&r.device));  // first use: the calling thread's current device is this library's from now on
   if (!r.stream) {
     HIP_OK(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&r.copy_stream, hipStreamNonBlocking));
@@ -277,7 +326,12 @@ int enqueue(const uint8_t *d_imgs, int n, int ncls, int32_t *d_classes, int16_t 
   hipError_t e;
   hipEvent_t *evs = nullptr;
   if (r.ws_pending && r.ws_last != s) {  // an earlier device-pointer call on another stream may still own the workspace
-    HIP_OK(hipStreamWaitEvent(s, r.ws_event, 0));
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
+    // A capturing stream must not wait on an event recorded outside its capture (the capture would be invalidated, or
+    // the dependency silently dropped on replay): settle the hand-over on the host before anything is recorded.
+    if (cap != hipStreamCaptureStatusNone) HIP_OK(hipEventSynchronize(r.ws_event));
+    else HIP_OK(hipStreamWaitEvent(s, r.ws_event, 0));
     r.ws_pending = false;
   }
   if (r.profiling) {
@@ -328,8 +382,10 @@ int infer_host(const uint8_t *imgs, int n, int ncls, int32_t *classes, int16_t *
   if (usec) *usec = 0.f;
   if (n <= 0) return 0;
   const size_t isz = (size_t)r.spec.image_bytes();
-  const int chunk = n < kHostChunk ? n : kHostChunk;
-  const int nchunks = (n + chunk - 1) / chunk;
+  // (the stage-output test hook reads the workspace after the call: all images must be in it, one chunk)
+  const std::vector<int> plan = plan_chunks(n, r.debug_last_stage >= 0);
+  const int chunk = largest_chunk(plan);
+  const int nchunks = (int)plan.size() - 1;
   if (reserve(chunk) || reserve_host(chunk, (size_t)n)) return -1;
   while ((int)r.time_events.size() < 2 * nchunks) {
     hipEvent_t e;
@@ -342,7 +398,7 @@ int infer_host(const uint8_t *imgs, int n, int ncls, int32_t *classes, int16_t *
   // every chunk stay in HBM and come back in one transfer at the end (a D2H into pageable memory
   // would otherwise make the host wait for each chunk's kernels before it can queue the next copy).
   for (int c = 0; c < nchunks; c++) {
-    const int base = c * chunk, m = (n - base < chunk) ? n - base : chunk, slot = c & 1;
+    const int base = plan[c], m = plan[c + 1] - plan[c], slot = c & 1;
     if (nchunks == 1) {  // nothing to overlap: stay on one stream (fewer driver round trips for small calls)
       HIP_OK(hipMemcpyAsync(r.d_images[slot], imgs, (size_t)m * isz, hipMemcpyHostToDevice, r.stream));
     } else {
@@ -484,16 +540,17 @@ struct ChunkReader {
   ~ChunkReader() { (void)wait(); }
 };
 
-// Streams images [0, n) of an open file into HBM, a chunk of at most kHostChunk at a time (reader
-// threads one chunk ahead of the copy).  Chunk c lands packed (labels stripped) at dst(c, slot) and
+// Streams images [0, n) of an open file into HBM, chunk by chunk (plan_chunks; reader
+// threads one chunk ahead of the copy).  Chunk c lands packed (labels stripped) at dst(base, slot) and
 // `consume(c, base, m, slot)` is called once its copy and strip are enqueued on copy_stream and
 // r.stream has been made to wait for them.  reuse_slots: the destinations alternate between two
 // buffers, so a chunk's copy must wait until the stages of the chunk two before have consumed it.
 template <typename Dst, typename Consume>
 int stream_file(const ImageFile &f, int n, bool reuse_slots, Dst dst, Consume consume) {
   Runtime &r = rt();
-  const int chunk = n < kHostChunk ? n : kHostChunk;
-  const int nchunks = (n + chunk - 1) / chunk;
+  const std::vector<int> plan = plan_chunks(n, false);
+  const int chunk = largest_chunk(plan);
+  const int nchunks = (int)plan.size() - 1;
   const size_t chunk_bytes = (size_t)chunk * f.rec;
   if (chunk_bytes > r.file_cap) {
     HIP_OK(hipDeviceSynchronize());
@@ -513,16 +570,15 @@ int stream_file(const ImageFile &f, int n, bool reuse_slots, Dst dst, Consume co
   }
   ChunkReader reader;
   auto span = [&](int c, size_t *off, int *m) {
-    const int base = c * chunk;
-    *m = (n - base < chunk) ? n - base : chunk;
-    *off = f.first + (size_t)base * f.rec;
+    *m = plan[c + 1] - plan[c];
+    *off = f.first + (size_t)plan[c] * f.rec;
   };
   size_t off;
   int m;
   span(0, &off, &m);
   reader.start(f.fd, off, (size_t)m * f.rec, r.h_file[0].get());
   for (int c = 0; c < nchunks; c++) {
-    const int base = c * chunk, slot = c & 1;
+    const int base = plan[c], slot = c & 1;
     span(c, &off, &m);
     if (!reader.wait()) return fail("input file: read error");
     if (c + 1 < nchunks) {  // the other host chunk is free once its copy (chunk c-1) has left it
@@ -535,7 +591,7 @@ int stream_file(const ImageFile &f, int n, bool reuse_slots, Dst dst, Consume co
     // one chunk: nothing to overlap, stay on the compute stream (fewer driver round trips for small calls)
     hipStream_t cs = (nchunks == 1 && reuse_slots) ? r.stream : r.copy_stream;
     if (c >= 2) HIP_OK(hipStreamWaitEvent(cs, r.consumed[slot], 0));  // d_file[slot] / dst free again
-    uint8_t *packed = dst(c, slot);
+    uint8_t *packed = dst(base, slot);
     uint8_t *to = f.skip ? r.d_file[slot] : packed;
     HIP_OK(hipMemcpyAsync(to, r.h_file[slot].get(), (size_t)m * f.rec, hipMemcpyHostToDevice, cs));
     if (nchunks > 1) HIP_OK(hipEventRecord(r.file_sent[slot], cs));
@@ -562,8 +618,9 @@ int infer_file(const ImageFile &f, int n, int ncls, int32_t *classes, int16_t *s
   if (ncls < 1 || ncls > 64) return fail("number_class must be in 1..64");
   if (usec) *usec = 0.f;
   if (n <= 0) return 0;
-  const int chunk = n < kHostChunk ? n : kHostChunk;
-  const int nchunks = (n + chunk - 1) / chunk;
+  const std::vector<int> plan = plan_chunks(n, false);  // (stream_file walks the same plan)
+  const int chunk = largest_chunk(plan);
+  const int nchunks = (int)plan.size() - 1;
   if (reserve(chunk) || reserve_host(chunk, (size_t)n)) return -1;
   while ((int)r.time_events.size() < 2 * nchunks) {
     hipEvent_t e;
@@ -606,7 +663,7 @@ int load_file_resident(const ImageFile &f, int n) {
   if (bind_device() || grow(r.d_all, r.all_cap, (size_t)n * isz + 256)) return -1;
   DrainOnFailure drain;
   if (stream_file(
-          f, n, false, [&](int c, int) { return r.d_all + (size_t)c * kHostChunk * isz; }, [&](int, int, int, int) { return 0; }))
+          f, n, false, [&](int base, int) { return r.d_all + (size_t)base * isz; }, [&](int, int, int, int) { return 0; }))
     return -1;
   HIP_OK(hipStreamSynchronize(r.copy_stream));
   drain.ok();
@@ -841,7 +898,11 @@ const char *bnn_mi355x_last_error(void) { return rt().err.c_str(); }
 
 int bnn_mi355x_set_device(int ordinal) {
   Runtime &r = rt();
-  if (r.d_blob || r.cap || r.stage_cap) return fail("set_device must be called before load_parameters");
+  if (r.d_blob || r.cap || r.stage_cap || r.stream) {
+    if (ordinal == r.device) return 0;  // already bound to exactly this device: nothing to do
+    return fail("set_device must be called before load_parameters (this library is bound to device " + std::to_string(r.device) + ")");
+  }
+  if (ordinal < 0) return fail("set_device: negative ordinal");
   r.device = ordinal;
   return 0;
 }
@@ -932,6 +993,13 @@ int bnn_mi355x_inference_raw(const uint8_t *images, int n_images, int16_t *score
 }
 
 int bnn_mi355x_reserve(int max_images) { return ready() ? reserve(max_images) : -1; }
+
+int bnn_mi355x_chunk_plan(int n_images, int *bases, int cap) {
+  if (n_images < 0) return fail("chunk_plan: bad arguments");
+  const std::vector<int> plan = plan_chunks(n_images, false);
+  for (size_t i = 0; i < plan.size() && (int)i < cap && bases; i++) bases[i] = plan[i];
+  return (int)plan.size();
+}
 
 long bnn_mi355x_debug_stage_output(const uint8_t *images, int n_images, int stage, void *dst, size_t cap) {
   Runtime &r = rt();
@@ -1100,6 +1168,11 @@ int bnn_mi355x_inference_device(const void *d_images, int n_images, int number_c
   if (!ready()) return -1;
   if (n_images < 0 || (n_images > 0 && !d_images)) return fail("inference_device: bad arguments");
   if (number_class < 1 || number_class > 64) return fail("number_class must be in 1..64");
+  // the kernels read images with 128-bit loads and write scores as dwords (include/bnn_mi355x.h states the alignment)
+  auto misaligned = [](const void *p, uintptr_t a) { return p && (reinterpret_cast<uintptr_t>(p) & (a - 1)) != 0; };
+  if (misaligned(d_images, 16)) return fail("inference_device: d_images must be 16-byte aligned");
+  if (misaligned(d_classes, 4) || misaligned(d_scores, 4) || misaligned(d_words, 8))
+    return fail("inference_device: d_classes / d_scores must be 4-byte aligned, d_words 8-byte aligned");
   // the device-side LFC decode is an exact integer floor(log2); the reference's (unsigned) log2((double) word)
   // rounds UP for some words of 48 bits and more, which only the host decode (libm) reproduces
   if (!r.spec.is_cnv && d_classes && number_class > 47)

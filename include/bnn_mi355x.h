@@ -85,7 +85,9 @@ int bnn_mi355x_image_bytes(void);
 const char *bnn_mi355x_last_error(void);
 
 /* select the GPU (HIP ordinal) used by this library instance; call before
- * load_parameters.  Returns 0 on success. */
+ * load_parameters.  Returns 0 on success.  Without the call the library binds to the calling thread's
+ * current device at its first use.  Once bound, set_device(the bound ordinal) is a no-op returning 0 and any
+ * other ordinal is an error (-1 + last_error). */
 int bnn_mi355x_set_device(int ordinal);
 
 /* Packed parameter blob (position-independent bytes, see csrc/packed_params.h).
@@ -122,19 +124,31 @@ int bnn_mi355x_inference_raw(const uint8_t *images, int n_images, int16_t *score
 /* Classify n images already resident in HBM, asynchronously on `hip_stream`
  * (a hipStream_t, NULL = the default stream).  d_classes: int32[n] (batched
  * decode); d_scores (CNV, optional): int16[n*64]; d_words (LFC, optional):
- * uint64[n].  All device pointers.  The workspace grows on demand (which
+ * uint64[n].  All device pointers.  Alignment: d_images 16 bytes (every image then is: 3072 and 784 are
+ * multiples of 16; the kernels read them with 128-bit loads), d_classes and d_scores 4 bytes, d_words 8 bytes;
+ * a misaligned pointer is refused (-1 + last_error), nothing is launched.  The workspace grows on demand (which
  * synchronises); call bnn_mi355x_reserve first to keep the call fully
  * asynchronous / graph-capturable.  Returns 0 on success.
  * One activation workspace per library instance: calls are serialised on the device -- a call on another
  * stream than the previous one first waits (hipStreamWaitEvent) for that call's kernels -- so they never
- * race, but they do not overlap either; a captured graph must not be replayed concurrently with other calls
- * into the same library.  The calling thread's current device is switched to this library's.
+ * race, but they do not overlap either (a stream handed in here must stay alive until its work is done: the
+ * previous call's stream is recognised by its handle).  While `hip_stream` is being captured into a graph the
+ * hand-over from an earlier call on another stream is settled on the host (the call blocks until that call's
+ * kernels are done) and nothing from outside the capture is recorded into it; a captured graph must not be
+ * replayed concurrently with other calls into the same library.  The calling thread's current device is switched to this library's.
  * LFC with d_classes: number_class <= 47 (the device decode is an exact floor(log2); the reference's
  * (unsigned) log2((double) word) differs from it for some words of 48 and more bits, which only the host
  * decode of inference_multiple / inference_buffer reproduces); take d_words beyond that. */
 int bnn_mi355x_inference_device(const void *d_images, int n_images, int number_class, int32_t *d_classes,
                                 int16_t *d_scores, uint64_t *d_words, void *hip_stream);
 int bnn_mi355x_reserve(int max_images);
+
+/* How the entry points that take HOST data (inference_multiple(path), inference_buffer, inference_raw) cut a
+ * call of n images into chunks whose transfer overlaps the previous chunk's stages: writes the chunk
+ * boundaries base[0] = 0 < base[1] < ... < base[k] = n (at most cap of them) and returns k + 1.  Small chunks
+ * at both ends (the first transfer and the last chunk's stages are the only parts nothing overlaps), 32 768
+ * images in between.  Host only; results never depend on the plan (tests/test_gpu_parity.py walks its edges). */
+int bnn_mi355x_chunk_plan(int n_images, int *bases, int cap);
 
 /* Fault campaigns: fix the seed of the fault planner (0 = std::random_device like the
  * reference, the default) and read back the faults of the last

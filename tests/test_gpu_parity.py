@@ -386,6 +386,14 @@ def test_file_abi_streams_multi_chunk_files(network, dataset, n, tmp_path):
     got = np.ctypeslib.as_array(p, (n,)).copy()
     L.free_results(p)
     assert (got == want).all()
+    # both entry points cut the call by the same plan (ramped chunks): the images either side of every chunk edge,
+    # against the oracle, which knows nothing of chunks
+    bases = (C.c_int * 64)()
+    k = L.bnn_mi355x_chunk_plan(n, bases, 64)
+    edges = [bases[i] for i in range(k)]
+    assert k >= 4 and edges[0] == 0 and edges[-1] == n and all(0 < b - a <= 32768 for a, b in zip(edges, edges[1:]))
+    near = sorted({min(max(e + d, 0), n - 1) for e in edges for d in (-2, -1, 0, 1)})
+    assert (got[near] == oracle(network, dataset).classes_batched(imgs[near], 10)).all()
     if cnv:
         p = L.inference_multiple(str(path).encode(), 10, C.byref(cnt), None, 1)
         det = np.ctypeslib.as_array(p, (n * 10,)).copy().reshape(n, 10)
@@ -633,3 +641,74 @@ def test_lfc_block_kernel_beyond_its_policy_range():
         "print('block-ok')\n" % (os.path.join(gl.ROOT, "tests"), os.path.join(gl.ROOT, "bnn-pynq_amd")))
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BNN_MI355X_LFC_BLOCK_MAX="1000000"), capture_output=True, text=True, timeout=600)
     assert "block-ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+
+
+def test_set_device_is_idempotent_once_bound():
+    """a second set_device to the ordinal the library is bound to answers 0 (bench.py's other_configs reuse a loaded
+    library); any other ordinal is an error"""
+    net = gpu_net("lfcW1A1", "mnist")
+    L = net.L
+    assert L.bnn_mi355x_set_device(0) == 0
+    assert L.bnn_mi355x_set_device(1) != 0 and b"bound to device 0" in L.bnn_mi355x_last_error()
+    imgs = rand_images("lfcW1A1", 100, 1)
+    assert (net.raw(imgs) == oracle("lfcW1A1", "mnist").words_fast(imgs)).all()
+
+
+def test_device_entry_point_refuses_misaligned_pointers():
+    """the kernels read images with 128-bit loads: d_images must be 16-byte aligned (include/bnn_mi355x.h); a
+    misaligned pointer is refused before anything is launched, an aligned view of the same data is classified"""
+    import torch
+    for network, dataset, isz in (("cnvW1A1", "cifar10", 3072), ("lfcW1A1", "mnist", 784)):
+        net = gpu_net(network, dataset)
+        n = 300
+        imgs = rand_images(network, n, 8)
+        raw = torch.zeros(n * isz + 64, dtype=torch.uint8, device="cuda")
+        cls = torch.full((n + 1,), -1, dtype=torch.int32, device="cuda")
+        for off in (1, 4, 8):
+            raw[off:off + n * isz] = torch.from_numpy(imgs.reshape(-1)).cuda()
+            assert net.L.bnn_mi355x_inference_device(raw.data_ptr() + off, n, 10, cls.data_ptr(), None, None, None) != 0
+            assert b"16-byte aligned" in net.L.bnn_mi355x_last_error()
+        raw[16:16 + n * isz] = torch.from_numpy(imgs.reshape(-1)).cuda()
+        assert net.L.bnn_mi355x_inference_device(raw.data_ptr() + 16, n, 10, cls.data_ptr() + 2, None, None, None) != 0   # classes: 4 bytes
+        assert net.L.bnn_mi355x_inference_device(raw.data_ptr() + 16, n, 10, cls.data_ptr() + 4, None, None, None) == 0
+        torch.cuda.synchronize()
+        assert int(cls[0]) == -1 and cls[1:].cpu().numpy().tolist() == oracle(network, dataset).classes_batched(imgs, 10).tolist()
+
+
+def test_device_call_captured_into_a_graph_after_a_call_on_another_stream():
+    """the header promises bnn_mi355x_inference_device is graph-capturable once the workspace is reserved.  The hard
+    case: an earlier call on stream A is still in flight (it owns the shared workspace) when a call on stream B is
+    CAPTURED -- the hand-over must be resolved before the capture starts recording (host-side wait), not by a
+    stream-wait on an event from outside the capture.  The graph is then replayed on fresh inputs."""
+    import torch
+    net = gpu_net("cnvW1A1", "cifar10")
+    L = net.L
+    o = oracle("cnvW1A1", "cifar10")
+    n = 2000
+    a_host, b_host, c_host = (rand_images("cnvW1A1", n, 700 + k) for k in range(3))
+    d_a = torch.from_numpy(a_host).cuda()
+    d_b = torch.from_numpy(b_host).cuda()
+    out_a = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    out_b = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    assert L.bnn_mi355x_reserve(n) == 0
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(4):   # keep stream A busy with the workspace
+        assert L.bnn_mi355x_inference_device(d_a.data_ptr(), n, 10, out_a.data_ptr(), None, None, sa.cuda_stream) == 0
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=sb):
+        rc = L.bnn_mi355x_inference_device(d_b.data_ptr(), n, 10, out_b.data_ptr(), None, None, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, L.bnn_mi355x_last_error()
+    torch.cuda.synchronize()
+    assert (out_a.cpu().numpy() == o.classes_batched(a_host, 10)).all()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert (out_b.cpu().numpy() == o.classes_batched(b_host, 10)).all()
+    d_b.copy_(torch.from_numpy(c_host).cuda())          # same graph, new images in the captured buffer
+    graph.replay()
+    torch.cuda.synchronize()
+    assert (out_b.cpu().numpy() == o.classes_batched(c_host, 10)).all()
+    # and an ordinary call afterwards still works
+    assert L.bnn_mi355x_inference_device(d_a.data_ptr(), n, 10, out_a.data_ptr(), None, None, None) == 0
+    torch.cuda.synchronize()
+    assert (out_a.cpu().numpy() == o.classes_batched(a_host, 10)).all()
