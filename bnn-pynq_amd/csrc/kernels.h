@@ -38,6 +38,9 @@ struct LfcLaunch {
   int last_stage;             // run stages 0..last_stage only; kLfcStages-1 = all
 };
 
+// layer-0 MFMA table (packed_params.h): the tile-form operands sit behind the pixel-form ones
+constexpr int kL0TileOffset = 2 * 64 * 32, kL0BigBytes = 2 * 32 * 2 * 16;
+
 constexpr int kCnvStages = 9;  // conv0, L1..L7, L8+decode
 constexpr int kLfcStages = 6;  // binarize, L0..L3, decode
 const char *stage_name(bool is_cnv, int stage);

@@ -357,6 +357,110 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv0_mfma(const uint8_t *__restr
 }
 
 // ---------------------------------------------------------------------------
+// Stage 0 on the matrix pipe, throughput form (round 3).  k_conv0_mfma above spends 209 VALU instructions per
+// 64-pixel wave, 105 of them on the window gather: every input byte is fetched by up to 9 lanes and quantised in
+// up to 9 windows, and the 3-byte runs are compacted into the K = 32 operand with v_alignbyte / v_perm.  Here a
+// block stages kL0Imgs images in LDS ONCE -- coalesced 16-byte loads, every byte quantised once -- and a run
+// (c, ky) of a window is one unaligned ds_read_b32: its three taps plus a don't-care byte whose weight is 0.
+// No compaction: K grows from 32 to 48 (9 runs + the threshold constants, spread over v_mfma_i32_32x32x32_i8 and
+// v_mfma_i32_32x32x16_i8, operand layout in packed_params.h) -- the matrix pipe was 12 % busy.  A wave takes a
+// tile of 32 pixels x 64 neurons at a time: lane (r, h) fetches the half of pixel r's runs its K slots hold (no
+// v_permlane swaps of the operands), the A operands stay in registers for all the block's tiles, the table's
+// neuron order makes the 16 accumulators of a lane half 16 consecutive neurons (no shifts between nibbles), and
+// ONE v_permlane32_swap + OR leaves lane (r, h) with output dword h of pixel r.
+// ---------------------------------------------------------------------------
+constexpr int kL0Imgs = 8;
+typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+
+// sign bits of 16 accumulators -> bits 0..15 (register i -> bit i)
+__device__ __forceinline__ uint32_t sign_bits16(const v16i &acc) {
+  uint32_t x = 0;
+#pragma unroll
+  for (int i = 15; i >= 0; i--) x = shift_in_sign(x, acc[i]);
+  return x;
+}
+// lanes 0..31 contribute `a`, lanes 32..63 `b`; lane (r, h): (a of lane r | a of lane r + 32) for h = 0, the same of b for h = 1
+__device__ __forceinline__ uint32_t merge_halves(uint32_t a, uint32_t b) {
+  const auto sw = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  return sw[0] | sw[1];
+}
+
+template <bool OUT2>
+__global__ __launch_bounds__(kBlock, 2) void k_conv0_tile(const uint8_t *__restrict__ imgs, uint32_t *__restrict__ out,
+                                                        const uint8_t *__restrict__ l0tab, int n_images) {
+  __shared__ uint4 q4[kL0Imgs * 192 + 1];  // quantised images, planar CHW int8 (+ the last run's don't-care byte)
+  const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int img0 = blockIdx.x * kL0Imgs;
+  const int cnt = __builtin_amdgcn_readfirstlane(min(kL0Imgs, n_images - img0));  // >= 1 by the grid size
+  const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(imgs + (size_t)img0 * 3072);
+  for (int i = tid; i < cnt * 192; i += kBlock) {
+    uint4 v = src[i];
+    v.x = quantise4(v.x); v.y = quantise4(v.y); v.z = quantise4(v.z); v.w = quantise4(v.w);
+    q4[i] = v;
+  }
+  if (tid == 0) q4[cnt * 192] = make_uint4(0, 0, 0, 0);
+  // A operands (loop-invariant): 16 + 8 (+ 8) bytes per lane and neuron tile
+  const uint8_t *__restrict__ tab = l0tab + kL0TileOffset;
+  v4i abig[2];
+  long asm0[2], asm1[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ct++) {
+    abig[ct] = *reinterpret_cast<const v4i *>(tab + ((ct * 32 + r) * 2 + h) * 16);
+    asm0[ct] = *reinterpret_cast<const long *>(tab + kL0BigBytes + (((0 * 2 + ct) * 32 + r) * 2 + h) * 8);
+    asm1[ct] = OUT2 ? *reinterpret_cast<const long *>(tab + kL0BigBytes + (((1 * 2 + ct) * 32 + r) * 2 + h) * 8) : 0;
+  }
+  __syncthreads();
+  const uint8_t *qb = reinterpret_cast<const uint8_t *>(q4);
+  const v16i zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int T = wave; T < cnt * 29; T += kBlock / 64) {  // 29 tiles of 32 pixels per image (the last holds 4)
+    const int gi = T / 29, t = T - gi * 29;             // wave-uniform
+    const int p = 32 * t + r, pc = p < 900 ? p : 899;    // ragged last tile: duplicate, store guarded
+    const int off = pc + 2 * (int)(__umul24((uint32_t)pc, 2185u) >> 16);  // 32 * oy + ox  (pc / 30 by multiply-shift, exact below 960)
+    const uint8_t *base = qb + gi * 3072 + off;
+    const uint8_t *b1 = base + h * 1024, *b2 = base + h * 32;
+    v4i bb;
+    bb[0] = (int)*reinterpret_cast<const u32_unaligned *>(b1);          // h = 0: runs (0,0) (0,1) (0,2) (2,0)
+    bb[1] = (int)*reinterpret_cast<const u32_unaligned *>(b1 + 32);     // h = 1: runs (1,0) (1,1) (1,2) (2,1)
+    bb[2] = (int)*reinterpret_cast<const u32_unaligned *>(b1 + 64);
+    bb[3] = (int)*reinterpret_cast<const u32_unaligned *>(b2 + 2048);
+    const uint32_t last = *reinterpret_cast<const u32_unaligned *>(base + 2112);  // run (2,2)
+    const long bs = (long)(uint64_t)(h ? 0x00004001u : last);           // h = 1: the constants 1 and 64
+    uint32_t x[2], y[2];
+    // both neuron tiles' products are issued before either is read: the second chain covers the first one's latency
+    v16i big[2], d0[2], d1[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++) big[ct] = __builtin_amdgcn_mfma_i32_32x32x32_i8(abig[ct], bb, zero, 0, 0, 0);
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++) {
+      d0[ct] = __builtin_amdgcn_mfma_i32_32x32x16_i8(asm0[ct], bs, big[ct], 0, 0, 0);  // dot - t0 - 1: sign = !fire
+      if constexpr (OUT2) d1[ct] = __builtin_amdgcn_mfma_i32_32x32x16_i8(asm1[ct], bs, big[ct], 0, 0, 0);  // second threshold
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ct++) {
+      if constexpr (!OUT2) {
+        x[ct] = sign_bits16(d0[ct]) << (16 * h);
+      } else {
+        const uint32_t n0 = sign_bits16(d0[ct]), n1 = sign_bits16(d1[ct]);
+        x[ct] = (n0 & n1) << (16 * h);  // sign plane: neither fired
+        y[ct] = (n0 ^ n1) << (16 * h);  // inverted non-zero plane
+      }
+    }
+    const size_t pix = (size_t)(img0 + gi) * 900 + p;
+    if constexpr (!OUT2) {
+      const uint32_t w = ~merge_halves(x[0], x[1]);  // collected !fire
+      if (p < 900) out[pix * 2 + h] = w;
+    } else {  // [pixel][C/64 = 1][plane][half]
+      const uint32_t sg = merge_halves(x[0], x[1]), nz = ~merge_halves(y[0], y[1]);
+      if (p < 900) {
+        out[pix * 4 + h] = sg;
+        out[pix * 4 + 2 + h] = nz;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // COMPARISON FIGURE, not the product path (BNN_MI355X_L1=lds): cnvW1A1 layer 1 written the way the north-star
 // words it -- weight tile staged in LDS with coalesced loads, 64-bit XNOR + __popcll, the threshold as a compare,
 // max-pool as a wavefront-shuffle reduction (lane = output pixel, the four pixels of a pooling quad on four
@@ -1670,6 +1774,15 @@ inline long long lfc_block_max() {
   return v;
 }
 
+// images: from here on layer 0 runs in its LDS-staged tile form (k_conv0_tile); BNN_MI355X_L0_TILE_MIN overrides
+inline long long l0_tile_min() {
+  static const long long v = [] {
+    const char *e = std::getenv("BNN_MI355X_L0_TILE_MIN");
+    return e ? std::atoll(e) : 2048LL;
+  }();
+  return v;
+}
+
 // neuron groups per block: all of them once the work items alone fill the chip (256 CUs x 8 blocks),
 // so that a lane writes whole output words and reads its window once; otherwise one (parallelism first)
 inline int gpb_for(long long items, int groups) { return (items + kBlock - 1) / kBlock >= 2048 ? groups : 1; }
@@ -1717,8 +1830,13 @@ void run_cnv_t(const CnvLaunch &a) {
   hipStream_t s = a.stream;
   BNN_MARK(a.events, 0, s);
   if (a.l0_mfma) {
+    // throughput form (images staged in LDS, a block per kL0Imgs images) once its grid fills the chip; below
+    // that the lane-per-pixel form, whose 15 waves per image spread over the CUs
     const dim3 g0((unsigned)((n * 900 + kBlock - 1) / kBlock));  // lane = pixel
-    if (a.last_stage >= 0) BNN_LAUNCH((k_conv0_mfma<OUT2>), g0, s, a.images, A, a.l0_mfma, (int)(n * 900));
+    if (a.last_stage >= 0) {
+      if (n >= l0_tile_min()) BNN_LAUNCH((k_conv0_tile<OUT2>), dim3((unsigned)((n + kL0Imgs - 1) / kL0Imgs)), s, a.images, A, a.l0_mfma, (int)n);
+      else BNN_LAUNCH((k_conv0_mfma<OUT2>), g0, s, a.images, A, a.l0_mfma, (int)(n * 900));
+    }
   } else {
     if (a.last_stage >= 0) BNN_LAUNCH((k_conv0<OUT2>), grid_for(n * 900, 2 / gpb_for(n * 900, 2)), s, a.images, A, a.rows[0], (int)(n * 900), 2, gpb_for(n * 900, 2));
   }

@@ -45,7 +45,7 @@ namespace bnn {
 
 constexpr uint32_t kBlobMagic0 = 0x4D4E4E42u;  // "BNNM"
 constexpr uint32_t kBlobMagic1 = 0x35353349u;  // "I355"
-constexpr uint32_t kBlobVersion = 3;
+constexpr uint32_t kBlobVersion = 4;
 
 struct PackedLayer {
   uint32_t offset;      // bytes from blob start, 256-byte aligned
@@ -67,7 +67,20 @@ struct PackedHeader {
 // product, +-3456): the first with t = t0, the second with t = t1 (second threshold of the 2-bit
 // nets; a copy of the first for the 1-bit net).  The activation operand carries the constants 1 and
 // 64 in K slots 27 and 28, so the MFMA result is  dot - t - 1 : its sign bit is !fire.
-constexpr uint32_t kL0MfmaBytes = 2 * 64 * 32;
+constexpr uint32_t kL0MfmaPixelBytes = 2 * 64 * 32;
+// Behind them, the same layer in the operand form of k_conv0_tile (kernels.hip), which feeds the matrix pipe
+// from quantised images staged in LDS: a 3-tap run (c, ky) of a window is ONE unaligned dword read -- its
+// three taps plus a don't-care byte whose weight is 0 -- so K grows to 9 runs + 1 constant dword and is
+// spread over a K = 32 and a K = 16 instruction (v_mfma_i32_32x32x32_i8 + v_mfma_i32_32x32x16_i8):
+//   big   [tile ct 0..1][row i 0..31][h 0..1][16 int8]   k = 16h + 4s + b: tap kx = b (b < 3, else 0) of run
+//         R[h][s], R[0] = (c,ky) (0,0) (0,1) (0,2) (2,0), R[1] = (1,0) (1,1) (1,2) (2,1)
+//   small [threshold 0..1][ct][row i][h][8 int8]   h = 0: taps of run (2,2), 0...; h = 1: a0, a1, 0... (a0 +
+//         64*a1 = -t - 1 as above, against the activation constants 1 and 64)
+// Row i of tile ct is neuron 32ct + 16h' + 4g + q with i = 8g + 4h' + q: lane half h' of the MFMA result then
+// holds, in register order, 16 CONSECUTIVE neurons -- their sign bits need no interleaving.
+constexpr uint32_t kL0MfmaBigBytes = 2 * 32 * 2 * 16, kL0MfmaSmallBytes = 2 * 2 * 32 * 2 * 8;
+constexpr uint32_t kL0MfmaTileOffset = kL0MfmaPixelBytes;  // from l0_mfma_offset
+constexpr uint32_t kL0MfmaBytes = kL0MfmaPixelBytes + kL0MfmaBigBytes + kL0MfmaSmallBytes;
 static_assert(sizeof(PackedHeader) == 32 + 9 * 16, "blob header layout");
 
 uint32_t row_dwords_for(const LayerSpec &L);

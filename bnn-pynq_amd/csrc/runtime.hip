@@ -330,8 +330,19 @@ int enqueue(const uint8_t *d_imgs, int n, int ncls, int32_t *d_classes, int16_t 
     if (hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
     // A capturing stream must not wait on an event recorded outside its capture (the capture would be invalidated, or
     // the dependency silently dropped on replay): settle the hand-over on the host before anything is recorded.
-    if (cap != hipStreamCaptureStatusNone) HIP_OK(hipEventSynchronize(r.ws_event));
-    else HIP_OK(hipStreamWaitEvent(s, r.ws_event, 0));
+    if (cap != hipStreamCaptureStatusNone) {
+      // (a host-side wait is "unsafe" under the global capture mode frameworks use: switch this thread to the relaxed
+      // mode around it -- the wait is on work submitted before the capture began, which is exactly the safe case)
+      hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+      HIP_OK(hipThreadExchangeStreamCaptureMode(&mode));
+      const hipError_t we = hipEventSynchronize(r.ws_event);
+      (void)hipThreadExchangeStreamCaptureMode(&mode);
+      if (we != hipSuccess)
+        return fail("inference_device: an earlier call on another stream still owns the workspace and cannot be waited for during "
+                    "stream capture; synchronise that stream before capturing");
+    } else {
+      HIP_OK(hipStreamWaitEvent(s, r.ws_event, 0));
+    }
     r.ws_pending = false;
   }
   if (r.profiling) {

@@ -92,7 +92,7 @@ def test_faulty_blob_matches_oracle_memories(network, dataset):
     same = np.ones(size, bool)
     l0m = struct.unpack_from("<I", blob, 24)[0]
     if l0m:
-        same[l0m: l0m + 2 * 64 * 32] = False
+        same[l0m: l0m + 2 * 64 * 32 + 4096] = False      # pixel-form and tile-form operands
     for l, n in touched:
         off, rd, rows, kw = struct.unpack_from("<4I", blob, 32 + 16 * l)
         same[off + n * rd * 4: off + (n + 1) * rd * 4] = False

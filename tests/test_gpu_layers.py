@@ -114,3 +114,56 @@ def test_layer1_matrix_pipe_experiment_is_bit_exact(tmp_path, mode):
         "print('alt-l1-ok')\n" % (os.path.join(gl.ROOT, "tests"), os.path.join(gl.ROOT, "bnn-pynq_amd"), str(tmp_path)))
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BNN_MI355X_L1=mode), capture_output=True, text=True, timeout=900)
     assert "alt-l1-ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_layer0_tile_form_is_bit_exact(tmp_path):
+    """k_conv0_tile (layer 0 from LDS-staged, once-quantised images: the form used from 2048 images on), forced
+    onto small batches with BNN_MI355X_L0_TILE_MIN=1 so that the faithful scalar restatement can check every bit
+    of the stage's output: three CNV nets, shipped and random parameters, weights of -2, ragged blocks (1..17
+    images against blocks of 8), and the whole network's scores."""
+    import os
+    import subprocess
+    import sys
+
+    import random_params
+    dirs = {}
+    for k, net in enumerate(("cnvW1A1", "cnvW1A2", "cnvW2A2")):
+        d = tmp_path / net
+        d.mkdir()
+        random_params.make(str(d), net, 30 + k, **({"neg2": 0.04} if net == "cnvW2A2" else {}))
+        dirs[net] = str(d)
+    code = (
+        "import sys, numpy as np; sys.path[:0] = [%r, %r]\n"
+        "import torch, gpu_lib as gl, oracle_lib as ol\n"
+        "from test_gpu_layers import stage_output, unpack\n"
+        "dirs = %r\n"
+        "for net in ('cnvW1A1', 'cnvW1A2', 'cnvW2A2'):\n"
+        "    L = gl.load(net); planes = 2 if net.endswith('A2') else 1\n"
+        "    for pdir in (gl.param_dir('cifar10', net), dirs[net]):\n"
+        "        L.load_parameters(pdir.encode()); assert L.bnn_mi355x_last_error() == b''\n"
+        "        o = ol.Oracle(net, pdir)\n"
+        "        for n in (1, 7, 8, 9, 17):\n"
+        "            imgs = np.random.default_rng(70 + n).integers(0, 256, (n, 3072), dtype=np.uint8)\n"
+        "            imgs[0, :] = np.random.default_rng(n).choice(np.array([0, 1, 127, 128, 254, 255], np.uint8), 3072)\n"
+        "            raw = stage_output(L, imgs, 0)\n"
+        "            for i in sorted({0, n // 2, n - 1}):\n"
+        "                assert (unpack(raw[i], 900, 64, planes) == o.layer_ref(imgs[i], 0)).all(), (net, pdir, n, i)\n"
+        "        imgs = np.random.default_rng(9).integers(0, 256, (1003, 3072), dtype=np.uint8)\n"
+        "        net_ = gl.Net.__new__(gl.Net); net_.L, net_.network, net_.is_cnv, net_.isz = L, net, True, 3072\n"
+        "        assert (net_.raw(imgs) == o.scores_fast(imgs)).all(), (net, pdir)\n"
+        "print('tile-l0-ok')\n" % (os.path.join(gl.ROOT, "tests"), os.path.join(gl.ROOT, "bnn-pynq_amd"), dirs))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BNN_MI355X_L0_TILE_MIN="1"), capture_output=True, text=True, timeout=900)
+    assert "tile-l0-ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+@pytest.mark.parametrize("network", ["cnvW1A1", "cnvW1A2", "cnvW2A2"])
+def test_layer0_forms_agree_across_the_policy_edge(network):
+    """2047 images run layer 0 with a lane per pixel (k_conv0_mfma), 2048 and more from LDS-staged images
+    (k_conv0_tile, blocks of 8 images; 2051 leaves a block of 3): stage-0 bits of the same images equal in both"""
+    L = gl.load(network)
+    L.load_parameters(gl.param_dir("cifar10", network).encode())
+    imgs = np.random.default_rng(77).integers(0, 256, (2051, 3072), dtype=np.uint8)
+    tile = stage_output(L, imgs, 0)
+    pixel = stage_output(L, imgs[:2047], 0)
+    assert (tile[:2047] == pixel).all()
+    assert (stage_output(L, imgs[2040:], 0) == tile[2040:]).all()       # the ragged block's images, as a small batch

@@ -36,7 +36,7 @@ def test_blob_matches_oracle_weights(network, dataset):
     blob = gl.pack_params(network, gl.param_dir(dataset, network))
     o = ol.Oracle(network, ol.param_dir(dataset, network))
     magic0, magic1, version, net_id, nlayers, total, _, _ = struct.unpack_from("<8I", blob, 0)
-    assert (magic0, magic1, version) == (0x4D4E4E42, 0x35353349, 3)
+    assert (magic0, magic1, version) == (0x4D4E4E42, 0x35353349, 4)
     assert total == blob.size and nlayers == o.nl
     for l in range(nlayers):
         off, rd, rows, kw = struct.unpack_from("<4I", blob, 32 + 16 * l)
@@ -107,6 +107,23 @@ def test_layer0_mfma_table(network, dataset):
             t = o.L.bnn_oracle_threshold(o.h, 0, n, which if nthr == 2 else 0) >> 1
             tc = min(lim, max(-lim - 1, t))
             assert int(A[n, 27]) + 64 * int(A[n, 28]) == -tc - 1 and abs(int(A[n, 27])) <= 32
+    # the same numbers once more, in the operand form of k_conv0_tile (packed_params.h): K = 32 part "big"
+    # [ct][row i][h][16], K = 16 part "small" [threshold][ct][row i][h][8]; row i = 8g + 4h' + q of tile ct is neuron
+    # 32ct + 16h' + 4g + q; a run (c, ky) = its three kx taps + a zero-weight byte
+    P = [blob[off + w * 2048: off + (w + 1) * 2048].copy().view(np.int8).reshape(64, 32) for w in range(2)]
+    big = blob[off + 4096: off + 4096 + 2048].copy().view(np.int8).reshape(2, 32, 2, 4, 4)
+    small = blob[off + 6144: off + 6144 + 2048].copy().view(np.int8).reshape(2, 2, 32, 2, 8)
+    runs = [[0, 1, 2, 6], [3, 4, 5, 7]]
+    for ct in range(2):
+        for i in range(32):
+            n = 32 * ct + 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3)
+            for h in range(2):
+                for s_ in range(4):
+                    assert big[ct, i, h, s_, :3].tolist() == P[0][n, 3 * runs[h][s_]: 3 * runs[h][s_] + 3].tolist() and big[ct, i, h, s_, 3] == 0
+            for w in range(2):
+                assert small[w, ct, i, 0].tolist() == P[w][n, 24:27].tolist() + [0] * 5
+                assert small[w, ct, i, 1].tolist() == P[w][n, 27:29].tolist() + [0] * 6
+    assert sorted(32 * ct + 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3) for ct in range(2) for i in range(32)) == list(range(64))
     # clamping never changes a decision: |dot| <= 27 * 128 * max|w|  (ap_int<2> weights reach -2 under faults)
     d = np.arange(-lim, lim + 1)
     for t in (-(1 << 22), -lim - 2, -lim - 1, -lim, 0, lim - 1, lim, lim + 1, 1 << 22):

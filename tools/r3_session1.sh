@@ -8,6 +8,12 @@ mkdir -p $O
 cd $R
 timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > $O/tests.log 2>&1 || { tail -30 $O/tests.log; exit 1; }
 tail -3 $O/tests.log
+# layer 0: tile form (default from 2048 images) against the lane-per-pixel form, same box
+python3 tools/stage_times.py cnvW1A1 131072 2048 8192 > $O/l0_ab.txt 2>&1
+BNN_MI355X_L0_TILE_MIN=1000000000 python3 tools/stage_times.py cnvW1A1 131072 2048 8192 >> $O/l0_ab.txt 2>&1
+python3 tools/stage_times.py cnvW2A2 131072 >> $O/l0_ab.txt 2>&1
+BNN_MI355X_L0_TILE_MIN=1000000000 python3 tools/stage_times.py cnvW2A2 131072 >> $O/l0_ab.txt 2>&1
+cat $O/l0_ab.txt
 for plan in 0:0:32768 2048:4096:32768 2048:0:32768 4096:8192:32768 2048:4096:16384 1024:2048:32768; do
   BNN_MI355X_CHUNKS=$plan timeout -k 10 300 python3 tools/path_rates.py cnvW1A1 131072 >> $O/path_rates.txt 2>$O/path_rates.err
 done
