@@ -23,6 +23,7 @@ struct CnvLaunch {
   hipStream_t stream;
   hipEvent_t *events;         // optional: kCnvStages+1 events, recorded around every stage
   int last_stage;             // run stages 0..last_stage only (debug / per-layer tests); kCnvStages-1 = all
+  hipEvent_t t0, t1;          // optional (both or neither): the batch's device time is t0 -> t1 (see LfcLaunch)
 };
 
 struct LfcLaunch {
@@ -36,6 +37,11 @@ struct LfcLaunch {
   hipStream_t stream;
   hipEvent_t *events;         // optional: kLfcStages+1 events
   int last_stage;             // run stages 0..last_stage only; kLfcStages-1 = all
+  // optional (both or neither): the batch's device time is t0 -> t1.  Several launches: events recorded in front of
+  // the first and behind the last.  ONE launch (k_lfc_fused*, k_lfc_block_s): the dispatch's own start / end
+  // timestamps (hipExtLaunchKernelGGL) -- what a kernel trace reports for it -- instead of two more packets around
+  // it, whose processing would be booked as compute (3.5 us on a 7 us kernel).
+  hipEvent_t t0, t1;
 };
 
 // layer-0 MFMA table (packed_params.h): the tile-form operands sit behind the pixel-form ones

@@ -33,6 +33,7 @@
 //
 // Data layout in HBM: see DESIGN.md ("Data layout").
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <cstdlib>
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv0_mfma(const uint8_t *__restr
 // 64-pixel wave, 105 of them on the window gather: every input byte is fetched by up to 9 lanes and quantised in
 // up to 9 windows, and the 3-byte runs are compacted into the K = 32 operand with v_alignbyte / v_perm.  Here a
 // block stages kL0Imgs images in LDS ONCE -- coalesced 16-byte loads, every byte quantised once -- and a run
-// (c, ky) of a window is one unaligned ds_read_b32: its three taps plus a don't-care byte whose weight is 0.
+// (c, ky) of a window is one 4-byte fetch from LDS (two aligned dwords + v_alignbyte): its three taps plus a don't-care byte whose weight is 0.
 // No compaction: K grows from 32 to 48 (9 runs + the threshold constants, spread over v_mfma_i32_32x32x32_i8 and
 // v_mfma_i32_32x32x16_i8, operand layout in packed_params.h) -- the matrix pipe was 12 % busy.  A wave takes a
 // tile of 32 pixels x 64 neurons at a time: lane (r, h) fetches the half of pixel r's runs its K slots hold (no
@@ -370,7 +371,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv0_mfma(const uint8_t *__restr
 // ONE v_permlane32_swap + OR leaves lane (r, h) with output dword h of pixel r.
 // ---------------------------------------------------------------------------
 constexpr int kL0Imgs = 8;
-typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+constexpr int kL0Plane = 1024 + 64, kL0Image = 3 * kL0Plane;  // LDS bytes: channel planes padded so that the two lane halves
+                                                              // (a plane apart) read different banks
 
 // sign bits of 16 accumulators -> bits 0..15 (register i -> bit i)
 __device__ __forceinline__ uint32_t sign_bits16(const v16i &acc) {
@@ -384,11 +386,18 @@ __device__ __forceinline__ uint32_t merge_halves(uint32_t a, uint32_t b) {
   const auto sw = __builtin_amdgcn_permlane32_swap(a, b, false, false);
   return sw[0] | sw[1];
 }
+// the 4 bytes at LDS byte address base + OFF (OFF a multiple of 4, base any alignment): two aligned dwords (one
+// ds_read2_b32) and a v_alignbyte -- an unaligned ds_read_b32 is legal on gfx950 but executes lane by lane
+// (measured: the first version of this kernel, one unaligned read per run, took 1.98 ms against 0.78 ms)
+template <int OFF>
+__device__ __forceinline__ uint32_t lds_run(const uint32_t *aligned, uint32_t shift) {
+  return __builtin_amdgcn_alignbyte(aligned[OFF / 4 + 1], aligned[OFF / 4], shift);
+}
 
 template <bool OUT2>
 __global__ __launch_bounds__(kBlock, 2) void k_conv0_tile(const uint8_t *__restrict__ imgs, uint32_t *__restrict__ out,
                                                         const uint8_t *__restrict__ l0tab, int n_images) {
-  __shared__ uint4 q4[kL0Imgs * 192 + 1];  // quantised images, planar CHW int8 (+ the last run's don't-care byte)
+  __shared__ uint4 q4[kL0Imgs * kL0Image / 16];  // quantised images, planar CHW int8
   const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int img0 = blockIdx.x * kL0Imgs;
@@ -397,9 +406,9 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv0_tile(const uint8_t *__restr
   for (int i = tid; i < cnt * 192; i += kBlock) {
     uint4 v = src[i];
     v.x = quantise4(v.x); v.y = quantise4(v.y); v.z = quantise4(v.z); v.w = quantise4(v.w);
-    q4[i] = v;
+    const int g = i / 192, j = i - g * 192;                       // image, 16-byte piece of it
+    q4[(g * kL0Image + (j >> 6) * kL0Plane + (j & 63) * 16) >> 4] = v;  // 64 pieces per channel plane
   }
-  if (tid == 0) q4[cnt * 192] = make_uint4(0, 0, 0, 0);
   // A operands (loop-invariant): 16 + 8 (+ 8) bytes per lane and neuron tile
   const uint8_t *__restrict__ tab = l0tab + kL0TileOffset;
   v4i abig[2];
@@ -417,15 +426,18 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv0_tile(const uint8_t *__restr
     const int gi = T / 29, t = T - gi * 29;             // wave-uniform
     const int p = 32 * t + r, pc = p < 900 ? p : 899;    // ragged last tile: duplicate, store guarded
     const int off = pc + 2 * (int)(__umul24((uint32_t)pc, 2185u) >> 16);  // 32 * oy + ox  (pc / 30 by multiply-shift, exact below 960)
-    const uint8_t *base = qb + gi * 3072 + off;
-    const uint8_t *b1 = base + h * 1024, *b2 = base + h * 32;
+    // this lane's runs: h = 0: (c,ky) = (0,0) (0,1) (0,2) (2,0) and, for the K = 16 product, (2,1);
+    //                   h = 1: (1,0) (1,1) (1,2) (2,2) and the constants 1, 64
+    const uint32_t byte = (uint32_t)(gi * kL0Image + off + h * kL0Plane);
+    const uint32_t *al = reinterpret_cast<const uint32_t *>(qb + (byte & ~3u));  // shift: (byte & 3) in both halves (kL0Plane % 4 == 0)
+    const uint32_t *al2 = reinterpret_cast<const uint32_t *>(qb + ((byte & ~3u) - h * (kL0Plane - 64)));  // run (2,0) / (2,2): two rows apart
     v4i bb;
-    bb[0] = (int)*reinterpret_cast<const u32_unaligned *>(b1);          // h = 0: runs (0,0) (0,1) (0,2) (2,0)
-    bb[1] = (int)*reinterpret_cast<const u32_unaligned *>(b1 + 32);     // h = 1: runs (1,0) (1,1) (1,2) (2,1)
-    bb[2] = (int)*reinterpret_cast<const u32_unaligned *>(b1 + 64);
-    bb[3] = (int)*reinterpret_cast<const u32_unaligned *>(b2 + 2048);
-    const uint32_t last = *reinterpret_cast<const u32_unaligned *>(base + 2112);  // run (2,2)
-    const long bs = (long)(uint64_t)(h ? 0x00004001u : last);           // h = 1: the constants 1 and 64
+    bb[0] = (int)lds_run<0>(al, byte);
+    bb[1] = (int)lds_run<32>(al, byte);
+    bb[2] = (int)lds_run<64>(al, byte);
+    bb[3] = (int)lds_run<2 * kL0Plane>(al2, byte);
+    const uint32_t mid = lds_run<2 * kL0Plane + 32>(al2, byte);  // run (2,1) where h = 0
+    const long bs = (long)(uint64_t)(h ? 0x00004001u : mid);
     uint32_t x[2], y[2];
     // both neuron tiles' products are issued before either is read: the second chain covers the first one's latency
     v16i big[2], d0[2], d1[2];
@@ -1470,15 +1482,25 @@ __global__ __launch_bounds__(1024) void k_lfc_fused_a2(const uint8_t *__restrict
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, img0 = blockIdx.x * IPB;
   uint64_t w0[13], w1[16], w2[16], w3[16];
   int a0, b0, a1, b1, a2, b2, a3 = 0, b3 = 0;
-  lfc_load_row2<13>(r0, t, w0, a0, b0);
+  // (pixels first, all three big rows at entry for a single image: see k_lfc_fused)
+  constexpr bool ALL_ROWS = IPB == 1;
+  uint8_t px[IPB];
 #pragma unroll
   for (int i = 0; i < IPB; i++) {
     const int img = img0 + i < n_images ? img0 + i : n_images - 1;
-    const uint8_t px = (t < 784) ? imgs[(size_t)img * 784 + t] : 0;
-    const uint64_t word = __ballot(px >= 128);
+    px[i] = imgs[(size_t)img * 784 + (t < 784 ? t : 783)];
+  }
+  lfc_load_row2<13>(r0, t, w0, a0, b0);
+  if constexpr (ALL_ROWS) {
+    lfc_load_row2<16>(r1, t, w1, a1, b1);
+    lfc_load_row2<16>(r2, t, w2, a2, b2);
+  }
+#pragma unroll
+  for (int i = 0; i < IPB; i++) {
+    const uint64_t word = __ballot(px[i] >= 128 && t < 784);
     if (lane == 0) in0[i][wave] = word;
   }
-  lfc_load_row2<16>(r1, t, w1, a1, b1);
+  if constexpr (!ALL_ROWS) lfc_load_row2<16>(r1, t, w1, a1, b1);
   __syncthreads();
   // layer 0: XNOR inner product, two thresholds (pre-transformed: fire_i <=> m < t_i)
 #pragma unroll
@@ -1489,7 +1511,8 @@ __global__ __launch_bounds__(1024) void k_lfc_fused_a2(const uint8_t *__restrict
     const uint64_t f0 = __ballot(m < a0), f1 = __ballot(m < b0);
     if (lane == 0) { sg[0][i][wave] = ~(f0 | f1); nzp[0][i][wave] = ~(f0 ^ f1); }
   }
-  lfc_load_row2<16>(r2, t, w2, a2, b2);
+  if constexpr (!ALL_ROWS) lfc_load_row2<16>(r2, t, w2, a2, b2);
+  else if (wave == 0) lfc_load_row2<16>(r3, lane, w3, a3, b3);
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < IPB; i++) {
@@ -1497,7 +1520,9 @@ __global__ __launch_bounds__(1024) void k_lfc_fused_a2(const uint8_t *__restrict
     const uint64_t f0 = __ballot(q + a1 < 0), f1 = __ballot(q + b1 < 0);
     if (lane == 0) { sg[1][i][wave] = ~(f0 | f1); nzp[1][i][wave] = ~(f0 ^ f1); }
   }
-  if (wave == 0) lfc_load_row2<16>(r3, lane, w3, a3, b3);
+  if constexpr (!ALL_ROWS) {
+    if (wave == 0) lfc_load_row2<16>(r3, lane, w3, a3, b3);
+  }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < IPB; i++) {
@@ -1551,30 +1576,46 @@ __global__ __launch_bounds__(1024) void k_lfc_fused(const uint8_t *__restrict__ 
   // A row, once in VGPRs, serves all IPB images of the block.
   uint64_t w0[13], w1[16], w2[16], w3[16];
   int t0, t1, t2, t3 = 0;
-  lfc_load_row<13>(r0, t, w0, t0);
-  // binarizeAndPack: bit i = (pixel i >= 128); pixels 784..831 are padding (0)
+  // A single image is pure latency: four dependent layers behind one trip to L2 each.  With one image per block the
+  // rows of ALL layers are requested at entry (90 dwords per thread: the block has the CU to itself, 128 VGPRs);
+  // with more images per block two rows are in flight at a time (more would spill at two blocks per CU).
+  constexpr bool ALL_ROWS = IPB == 1;
+  // the pixels are requested first: vector loads return in order, so waiting for them must not mean waiting for rows
+  uint8_t px[IPB];
 #pragma unroll
   for (int i = 0; i < IPB; i++) {
     const int img = img0 + i < n_images ? img0 + i : n_images - 1;  // ragged tail: duplicate, store guarded
-    const uint8_t px = (t < 784) ? imgs[(size_t)img * 784 + t] : 0;
-    const uint64_t word = __ballot(px >= 128);
+    px[i] = imgs[(size_t)img * 784 + (t < 784 ? t : 783)];  // (unconditional: a branch would put the wait in front of the row loads)
+  }
+  lfc_load_row<13>(r0, t, w0, t0);
+  if constexpr (ALL_ROWS) {
+    lfc_load_row<16>(r1, t, w1, t1);
+    lfc_load_row<16>(r2, t, w2, t2);   // (layer 3's row -- wave 0 only -- takes layer 0's registers once they are free)
+  }
+  // binarizeAndPack: bit i = (pixel i >= 128); pixels 784..831 are padding (0)
+#pragma unroll
+  for (int i = 0; i < IPB; i++) {
+    const uint64_t word = __ballot(px[i] >= 128 && t < 784);
     if (lane == 0) act[0][i][wave] = word;  // waves 13..15 write zeros
   }
-  lfc_load_row<16>(r1, t, w1, t1);
+  if constexpr (!ALL_ROWS) lfc_load_row<16>(r1, t, w1, t1);
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < IPB; i++) {
     const uint64_t word = __ballot(lfc_fires<13>(w0, t0, act[0][i]));
     if (lane == 0) act[1][i][wave] = word;
   }
-  lfc_load_row<16>(r2, t, w2, t2);
+  if constexpr (!ALL_ROWS) lfc_load_row<16>(r2, t, w2, t2);
+  else if (wave == 0) lfc_load_row<16>(r3, lane, w3, t3);
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < IPB; i++) {
     const uint64_t word = __ballot(lfc_fires<16>(w1, t1, act[1][i]));
     if (lane == 0) act[0][i][wave] = word;
   }
-  if (wave == 0) lfc_load_row<16>(r3, lane, w3, t3);
+  if constexpr (!ALL_ROWS) {
+    if (wave == 0) lfc_load_row<16>(r3, lane, w3, t3);
+  }
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < IPB; i++) {
@@ -1629,12 +1670,23 @@ __device__ __forceinline__ void lfc_row_regs(const uint32_t *__restrict__ rows, 
     wh[k] = v.y;
   }
 }
+#ifndef BNN_LFC_CHAINS
+#define BNN_LFC_CHAINS 1
+#endif
+#ifdef BNN_LFC_STAMPS
+// diagnostic build only (tools/build_variant.sh ... -DBNN_LFC_STAMPS): wave 0 of every block of k_lfc_block_s writes the
+// 100 MHz wall clock at entry, behind each of the five hand-offs / layers, and at exit: where a launch's time goes
+__device__ unsigned long long g_lfc_stamps[1024 * 8];
+#define LFC_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_lfc_stamps[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define LFC_STAMP(i) do { } while (0)
+#endif
 typedef uint32_t v16u __attribute__((ext_vector_type(16)));
+// Both loads AND their wait in one statement, early-clobber outputs: the compiler can neither place `lo` over the
+// address pair the second load still reads, nor copy / spill the tuples between the loads and the wait.
 __device__ __forceinline__ void sload_image(const uint64_t *p, v16u &lo, v16u &hi) {  // p: wave-uniform
-  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=s"(lo), "=s"(hi) : "s"(p));
+  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)" : "=&s"(lo), "=&s"(hi) : "s"(p));
 }
-// (the loads' results must not be used before the wait: the in/out operands make every later use depend on it)
-__device__ __forceinline__ void swait_image(v16u &lo, v16u &hi) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(lo), "+s"(hi)); }
 // m - t of this thread's neuron for one image (its 32 dwords in SGPRs).  (Two neurons per thread -- 4 * KW
 // pairs per scalar-load wait, 512-thread blocks -- was measured too: 3 % faster at 131 072 images, 10 % slower at
 // 10 000, where this kernel is used.)
@@ -1643,6 +1695,18 @@ __device__ __forceinline__ int lfc_neuron_s(const uint32_t (&wl)[KW], const uint
                                             uint32_t &t) {
   auto word = [&](int d) { return d < 16 ? lo[d] : hi[d - 16]; };
   int m;
+#if BNN_LFC_CHAINS == 2
+  // diagnostic / A-B build: two accumulator chains (low and high dwords), one add at the end
+  int m2;
+  asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %4" : "+v"(t), "=v"(m) : "s"(word(0)), "v"(wl[0]), "v"(nt));
+  asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, 0" : "+v"(t), "=v"(m2) : "s"(word(1)), "v"(wh[0]));
+#pragma unroll
+  for (int k = 1; k < KW; k++) {
+    asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "+v"(t), "+v"(m) : "s"(word(2 * k)), "v"(wl[k]));
+    asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "+v"(t), "+v"(m2) : "s"(word(2 * k + 1)), "v"(wh[k]));
+  }
+  return m + m2;
+#else
   asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %4" : "+v"(t), "=v"(m) : "s"(word(0)), "v"(wl[0]), "v"(nt));
   asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "+v"(t), "+v"(m) : "s"(word(1)), "v"(wh[0]));
 #pragma unroll
@@ -1651,6 +1715,7 @@ __device__ __forceinline__ int lfc_neuron_s(const uint32_t (&wl)[KW], const uint
     asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "+v"(t), "+v"(m) : "s"(word(2 * k + 1)), "v"(wh[k]));
   }
   return m;
+#endif
 }
 
 #pragma clang diagnostic push
@@ -1681,7 +1746,6 @@ __device__ __forceinline__ void lfc_block_layer_s(const uint32_t *__restrict__ r
     // the block's own images.)
     for (int i = 0; i < m; i++) {
       sload_image(in + (size_t)(base + i) * 16, a_lo, a_hi);
-      swait_image(a_lo, a_hi);
       park_word(lo, hi, __ballot(lfc_neuron_s<KW>(wl, wh, nt, a_lo, a_hi, t) < 0), i);
     }
     if (lane < m) out[(size_t)(base + lane) * 16 + wave] = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
@@ -1707,6 +1771,7 @@ __global__ __launch_bounds__(1024, 2) void k_lfc_block_s(const uint8_t *__restri
   const int cnt = __builtin_amdgcn_readfirstlane(min(ipb, n_images - img0));  // block-uniform, >= 1 by the grid size
   uint64_t *A = gA + (size_t)img0 * 16, *B = gB + (size_t)img0 * 16;
   uint32_t t = chain_temp();
+  LFC_STAMP(0);
   // binarizeAndPack into A: one lane per output word (words 13..15 of an image are never read by layer 0)
   for (int idx = tid; idx < cnt * 16; idx += 1024) {
     const int i = idx >> 4, k = idx & 15;
@@ -1723,12 +1788,17 @@ __global__ __launch_bounds__(1024, 2) void k_lfc_block_s(const uint8_t *__restri
     A[idx] = word;
   }
   lfc_block_handoff();
+  LFC_STAMP(1);
   lfc_block_layer_s<13>(r0, tid, A, B, cnt, wave, lane, t);
+  LFC_STAMP(2);
   lfc_block_handoff();
+  LFC_STAMP(3);
   lfc_block_layer_s<16>(r1, tid, B, A, cnt, wave, lane, t);
   lfc_block_handoff();
+  LFC_STAMP(4);
   lfc_block_layer_s<16>(r2, tid, A, B, cnt, wave, lane, t);
   lfc_block_handoff();
+  LFC_STAMP(5);
   {  // layer 3 (64 neurons: neuron = lane in every wave) + decode: the waves share out the images
     uint32_t wl[16], wh[16];
     int nt;
@@ -1736,7 +1806,6 @@ __global__ __launch_bounds__(1024, 2) void k_lfc_block_s(const uint8_t *__restri
     v16u lo, hi;
     for (int i = wave; i < cnt; i += 16) {
       sload_image(B + (size_t)i * 16, lo, hi);
-      swait_image(lo, hi);
       const uint64_t word = __ballot(lfc_neuron_s<16>(wl, wh, nt, lo, hi, t) < 0);
       if (lane == 0) {
         words[img0 + i] = word;
@@ -1747,7 +1816,14 @@ __global__ __launch_bounds__(1024, 2) void k_lfc_block_s(const uint8_t *__restri
       }
     }
   }
+  LFC_STAMP(6);
 }
+
+#ifdef BNN_LFC_STAMPS
+}  // namespace
+hipError_t lfc_stamps_read(unsigned long long *dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_lfc_stamps), sizeof(g_lfc_stamps)); }
+namespace {
+#endif
 
 // LFC output decode, batched form (testPrebinarized_nolabel_multiple_images,
 // foldedmv-offload.cpp:202-220): mask to number_class bits, class = index of
@@ -1981,6 +2057,7 @@ void l1_mfma_table(const uint32_t *rows, uint8_t *dst) {
 
 hipError_t run_cnv(NetId net, const CnvLaunch &a) {
   if (a.n <= 0) return hipSuccess;
+  if (a.t0) (void)hipEventRecord(a.t0, a.stream);
   switch (net) {
     case NET_CNVW1A1: run_cnv_t<AR_XNOR, false>(a); break;
     case NET_CNVW1A2: run_cnv_t<AR_TB, true>(a); break;
@@ -1990,6 +2067,7 @@ hipError_t run_cnv(NetId net, const CnvLaunch &a) {
       break;
     default: return hipErrorInvalidValue;
   }
+  if (a.t1) (void)hipEventRecord(a.t1, a.stream);
   return hipGetLastError();
 }
 
@@ -2005,8 +2083,13 @@ hipError_t run_lfc(NetId net, const LfcLaunch &a) {
     // smallest that still fits the batch in one round of 256 blocks (profiles/r01_lfc_forms.txt).
     const int ipb = n <= 256 ? 1 : n <= 512 ? 2 : n <= 1024 ? 4 : 8;
     const dim3 g((unsigned)((n + ipb - 1) / ipb)), b(1024);
-#define BNN_FUSED(K, I) \
-  hipLaunchKernelGGL(K<I>, g, b, 0, s, a.images, a.words, a.classes, a.rows[0], a.rows[1], a.rows[2], a.rows[3], (int)n, a.number_class)
+#define BNN_FUSED(K, I)                                                                                                                   \
+  do {                                                                                                                                    \
+    if (a.t0) hipExtLaunchKernelGGL(K<I>, g, b, 0, s, a.t0, a.t1, 0, a.images, a.words, a.classes, a.rows[0], a.rows[1], a.rows[2],       \
+                                    a.rows[3], (int)n, a.number_class);                                                                   \
+    else hipLaunchKernelGGL(K<I>, g, b, 0, s, a.images, a.words, a.classes, a.rows[0], a.rows[1], a.rows[2], a.rows[3], (int)n,           \
+                            a.number_class);                                                                                              \
+  } while (0)
     if (net == NET_LFCW1A1) {
       if (ipb == 1) BNN_FUSED(k_lfc_fused, 1);
       else if (ipb == 2) BNN_FUSED(k_lfc_fused, 2);
@@ -2026,10 +2109,14 @@ hipError_t run_lfc(NetId net, const LfcLaunch &a) {
   if (net == NET_LFCW1A1 && n <= lfc_block_max() && !a.events && a.last_stage >= kLfcStages - 1) {
     // mid-size batch: two 1024-thread blocks per CU, each walking all four layers over its share of the images
     const int ipb = (int)((n + 511) / 512);
-    hipLaunchKernelGGL(k_lfc_block_s, dim3((unsigned)((n + ipb - 1) / ipb)), dim3(1024), 0, s, a.images, a.words, a.classes, A64, B64, a.rows[0],
-                       a.rows[1], a.rows[2], a.rows[3], (int)n, a.number_class, ipb);
+    const dim3 g((unsigned)((n + ipb - 1) / ipb)), b(1024);
+    if (a.t0) hipExtLaunchKernelGGL(k_lfc_block_s, g, b, 0, s, a.t0, a.t1, 0, a.images, a.words, a.classes, A64, B64, a.rows[0], a.rows[1],
+                                    a.rows[2], a.rows[3], (int)n, a.number_class, ipb);
+    else hipLaunchKernelGGL(k_lfc_block_s, g, b, 0, s, a.images, a.words, a.classes, A64, B64, a.rows[0], a.rows[1], a.rows[2], a.rows[3],
+                            (int)n, a.number_class, ipb);
     return hipGetLastError();
   }
+  if (a.t0) (void)hipEventRecord(a.t0, s);
   BNN_MARK(a.events, 0, s);
   if (a.last_stage >= 0) BNN_LAUNCH(k_lfc_binarize, grid_for(n * 13, 1), s, a.images, A64, (int)(n * 13));
   BNN_MARK(a.events, 1, s);
@@ -2057,6 +2144,7 @@ hipError_t run_lfc(NetId net, const LfcLaunch &a) {
   }
   if (a.classes && a.last_stage >= 5) BNN_LAUNCH(k_lfc_decode, grid_for(n, 1), s, a.words, a.classes, (int)n, a.number_class);
   BNN_MARK(a.events, 6, s);
+  if (a.t1) (void)hipEventRecord(a.t1, s);
   return hipGetLastError();
 }
 

@@ -172,7 +172,7 @@ void fill_l0_mfma(const NetSpec &net, const RawParams &raw, uint8_t *dst) {
   // the same numbers in the operand form of k_conv0_tile (packed_params.h)
   const int8_t *pix = reinterpret_cast<const int8_t *>(dst);
   int8_t *big = reinterpret_cast<int8_t *>(dst) + kL0MfmaTileOffset, *small = big + kL0MfmaBigBytes;
-  static const int run_of[2][4] = {{0, 1, 2, 6}, {3, 4, 5, 7}};  // run = c*3 + ky
+  static const int run_of[2][4] = {{0, 1, 2, 6}, {3, 4, 5, 8}};  // run = c*3 + ky; run 7 = (2,1) goes to the K = 16 product
   for (int ct = 0; ct < 2; ct++)
     for (int i = 0; i < 32; i++) {
       const int g = i >> 3, hh = (i >> 2) & 1, q = i & 3, n = 32 * ct + 16 * hh + 4 * g + q;
@@ -184,7 +184,7 @@ void fill_l0_mfma(const NetSpec &net, const RawParams &raw, uint8_t *dst) {
           int8_t *sm = small + (((which * 2 + ct) * 32 + i) * 2 + h) * 8;
           const int8_t *row = pix + which * 64 * 32 + n * 32;
           for (int k = 0; k < 8; k++) sm[k] = 0;
-          if (h == 0) { sm[0] = row[24]; sm[1] = row[25]; sm[2] = row[26]; }
+          if (h == 0) { sm[0] = row[21]; sm[1] = row[22]; sm[2] = row[23]; }
           else { sm[0] = row[27]; sm[1] = row[28]; }
         }
       }

@@ -73,8 +73,9 @@ constexpr uint32_t kL0MfmaPixelBytes = 2 * 64 * 32;
 // three taps plus a don't-care byte whose weight is 0 -- so K grows to 9 runs + 1 constant dword and is
 // spread over a K = 32 and a K = 16 instruction (v_mfma_i32_32x32x32_i8 + v_mfma_i32_32x32x16_i8):
 //   big   [tile ct 0..1][row i 0..31][h 0..1][16 int8]   k = 16h + 4s + b: tap kx = b (b < 3, else 0) of run
-//         R[h][s], R[0] = (c,ky) (0,0) (0,1) (0,2) (2,0), R[1] = (1,0) (1,1) (1,2) (2,1)
-//   small [threshold 0..1][ct][row i][h][8 int8]   h = 0: taps of run (2,2), 0...; h = 1: a0, a1, 0... (a0 +
+//         R[h][s], R[0] = (c,ky) (0,0) (0,1) (0,2) (2,0), R[1] = (1,0) (1,1) (1,2) (2,2)   (the two lane halves
+//         then read LDS addresses a channel plane / two image rows apart: different banks)
+//   small [threshold 0..1][ct][row i][h][8 int8]   h = 0: taps of run (2,1), 0...; h = 1: a0, a1, 0... (a0 +
 //         64*a1 = -t - 1 as above, against the activation constants 1 and 64)
 // Row i of tile ct is neuron 32ct + 16h' + 4g + q with i = 8g + 4h' + q: lane half h' of the MFMA result then
 // holds, in register order, 16 CONSECUTIVE neurons -- their sign bits need no interleaving.

@@ -115,6 +115,7 @@ struct Runtime {
   const uint8_t *l0_mfma = nullptr;  // layer 0 as an MFMA operand (CNV nets), unless BNN_MI355X_L0=valu
   uint8_t *d_l1_mfma = nullptr;      // cnvW1A1, BNN_MI355X_L1=mfma only: layer 1 as FP4 MFMA operands (side experiment)
   bool l1_mfma = false, l1_literal = false;  // BNN_MI355X_L1=mfma / =lds (comparison figures, never the default)
+  bool warmed = false;  // warm_up() has run since the last deinit()
   int two_rows = 0;  // rows holding a weight of -2 (2-bit-weight net under fault injection): kernels.hip, two_extra
   // workspace
   int cap = 0;
@@ -320,8 +321,9 @@ int reserve_host(int chunk, size_t n_total) {
 }
 
 // enqueue one chunk (n <= cap) whose images are already in HBM
+// t0 / t1 (optional): this chunk's device time is t0 -> t1 (kernels.h)
 int enqueue(const uint8_t *d_imgs, int n, int ncls, int32_t *d_classes, int16_t *d_scores, uint64_t *d_words,
-            hipStream_t s) {
+            hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
   Runtime &r = rt();
   hipError_t e;
   hipEvent_t *evs = nullptr;
@@ -364,6 +366,7 @@ int enqueue(const uint8_t *d_imgs, int n, int ncls, int32_t *d_classes, int16_t 
     a.has_two = r.two_rows > 0;
     a.scores = d_scores; a.classes = d_classes; a.number_class = ncls; a.stream = s; a.events = evs;
     a.last_stage = r.debug_last_stage >= 0 ? r.debug_last_stage : kCnvStages - 1;
+    a.t0 = t0; a.t1 = t1;
     e = run_cnv(r.spec.id, a);
   } else {
     LfcLaunch a{};
@@ -372,6 +375,7 @@ int enqueue(const uint8_t *d_imgs, int n, int ncls, int32_t *d_classes, int16_t 
     a.words = d_words;
     a.classes = d_classes; a.number_class = ncls; a.stream = s; a.events = evs;
     a.last_stage = r.debug_last_stage >= 0 ? r.debug_last_stage : kLfcStages - 1;
+    a.t0 = t0; a.t1 = t1;
     e = run_lfc(r.spec.id, a);
   }
   if (e != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(e));
@@ -418,11 +422,9 @@ int infer_host(const uint8_t *imgs, int n, int ncls, int32_t *classes, int16_t *
       HIP_OK(hipEventRecord(r.copied[slot], r.copy_stream));
       HIP_OK(hipStreamWaitEvent(r.stream, r.copied[slot], 0));
     }
-    HIP_OK(hipEventRecord(r.time_events[2 * c], r.stream));
     if (enqueue(r.d_images[slot], m, ncls, classes ? r.d_classes + base : nullptr, want_scores ? r.d_scores + (size_t)base * 64 : nullptr,
-                r.d_words + base, r.stream))
+                r.d_words + base, r.stream, r.time_events[2 * c], r.time_events[2 * c + 1]))
       return -1;
-    HIP_OK(hipEventRecord(r.time_events[2 * c + 1], r.stream));
     if (nchunks > 1) HIP_OK(hipEventRecord(r.consumed[slot], r.stream));
   }
   if (classes) HIP_OK(hipMemcpyAsync(classes, r.d_classes, (size_t)n * 4, hipMemcpyDeviceToHost, r.stream));
@@ -447,8 +449,7 @@ int infer_host(const uint8_t *imgs, int n, int ncls, int32_t *classes, int16_t *
 // thousand through the throughput forms, zeros in, results dropped.  Once per process.
 int warm_up() {
   Runtime &r = rt();
-  static bool warmed = false;
-  if (warmed || std::getenv("BNN_MI355X_NO_WARMUP")) return 0;
+  if (r.warmed || std::getenv("BNN_MI355X_NO_WARMUP")) return 0;
   const int big = 8192;
   const size_t isz = (size_t)r.spec.image_bytes();
   if (reserve(big) || reserve_host(big, (size_t)big)) return -1;
@@ -467,7 +468,7 @@ int warm_up() {
   HIP_OK(hipEventRecord(r.time_events[0], r.stream));
   HIP_OK(hipEventRecord(r.time_events[1], r.stream));
   HIP_OK(hipStreamSynchronize(r.stream));
-  warmed = true;
+  r.warmed = true;
   return 0;
 }
 
@@ -643,11 +644,9 @@ int infer_file(const ImageFile &f, int n, int ncls, int32_t *classes, int16_t *s
   const int rc = stream_file(
       f, n, true, [&](int, int slot) { return r.d_images[slot]; },
       [&](int c, int base, int m, int slot) {
-        HIP_OK(hipEventRecord(r.time_events[2 * c], r.stream));
         if (enqueue(r.d_images[slot], m, ncls, classes ? r.d_classes + base : nullptr, want_scores ? r.d_scores + (size_t)base * 64 : nullptr,
-                    r.d_words + base, r.stream))
+                    r.d_words + base, r.stream, r.time_events[2 * c], r.time_events[2 * c + 1]))
           return -1;
-        HIP_OK(hipEventRecord(r.time_events[2 * c + 1], r.stream));
         return 0;
       });
   if (rc) return -1;
@@ -730,6 +729,9 @@ int *classify_host(const uint8_t *imgs, int n, int ncls, float *usec, int enable
 }  // namespace
 }  // namespace bnn
 
+#ifdef BNN_LFC_STAMPS
+namespace bnn { hipError_t lfc_stamps_read(unsigned long long *dst); }
+#endif
 using namespace bnn;
 
 // ============================================================================ C ABI
@@ -895,7 +897,10 @@ int *inference_multiple_with_faults(const char *path, int number_class, int *ima
 
 void free_results(int *result) { delete[] result; }
 
-void deinit(void) { free_workspace(); }
+void deinit(void) {
+  free_workspace();
+  rt().warmed = false;  // the buffers the warm-up allocated are gone: the next load warms again
+}
 
 const char *bnn_mi355x_network(void) {
 #ifdef BNN_VARIANT
@@ -947,7 +952,8 @@ int bnn_mi355x_import_params(const void *src, size_t bytes) {
   r.raw = RawParams{};
   if (upload_blob()) { r.blob.clear(); return -1; }
   r.err.clear();
-  return warm_up();
+  (void)warm_up();  // like load_parameters: a failing warm-up is reported (stderr, last_error), the parameters are loaded
+  return 0;
 }
 
 size_t bnn_mi355x_params_bytes(void) { return blob_bytes(rt().spec); }
@@ -968,7 +974,8 @@ int bnn_mi355x_import_params_device(const void *d_src, size_t bytes, void *hip_s
   r.raw = RawParams{};
   if (upload_blob()) { r.blob.clear(); return -1; }
   r.err.clear();
-  return warm_up();
+  (void)warm_up();  // (as above)
+  return 0;
 }
 
 unsigned int bnn_mi355x_params_crc(void) {
@@ -1004,6 +1011,14 @@ int bnn_mi355x_inference_raw(const uint8_t *images, int n_images, int16_t *score
 }
 
 int bnn_mi355x_reserve(int max_images) { return ready() ? reserve(max_images) : -1; }
+
+#ifdef BNN_LFC_STAMPS
+// diagnostic build only: 1024 blocks x 8 wall-clock stamps (100 MHz) of the last k_lfc_block_s launch
+int bnn_mi355x_debug_lfc_stamps(unsigned long long *dst) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  return bnn::lfc_stamps_read(dst) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int bnn_mi355x_chunk_plan(int n_images, int *bases, int cap) {
   if (n_images < 0) return fail("chunk_plan: bad arguments");

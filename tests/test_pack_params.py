@@ -113,7 +113,7 @@ def test_layer0_mfma_table(network, dataset):
     P = [blob[off + w * 2048: off + (w + 1) * 2048].copy().view(np.int8).reshape(64, 32) for w in range(2)]
     big = blob[off + 4096: off + 4096 + 2048].copy().view(np.int8).reshape(2, 32, 2, 4, 4)
     small = blob[off + 6144: off + 6144 + 2048].copy().view(np.int8).reshape(2, 2, 32, 2, 8)
-    runs = [[0, 1, 2, 6], [3, 4, 5, 7]]
+    runs = [[0, 1, 2, 6], [3, 4, 5, 8]]
     for ct in range(2):
         for i in range(32):
             n = 32 * ct + 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3)
@@ -121,7 +121,7 @@ def test_layer0_mfma_table(network, dataset):
                 for s_ in range(4):
                     assert big[ct, i, h, s_, :3].tolist() == P[0][n, 3 * runs[h][s_]: 3 * runs[h][s_] + 3].tolist() and big[ct, i, h, s_, 3] == 0
             for w in range(2):
-                assert small[w, ct, i, 0].tolist() == P[w][n, 24:27].tolist() + [0] * 5
+                assert small[w, ct, i, 0].tolist() == P[w][n, 21:24].tolist() + [0] * 5
                 assert small[w, ct, i, 1].tolist() == P[w][n, 27:29].tolist() + [0] * 6
     assert sorted(32 * ct + 16 * ((i >> 2) & 1) + 4 * (i >> 3) + (i & 3) for ct in range(2) for i in range(32)) == list(range(64))
     # clamping never changes a decision: |dot| <= 27 * 128 * max|w|  (ap_int<2> weights reach -2 under faults)
