@@ -1678,8 +1678,12 @@ __device__ __forceinline__ void lfc_row_regs(const uint32_t *__restrict__ rows, 
 // 100 MHz wall clock at entry, behind each of the five hand-offs / layers, and at exit: where a launch's time goes
 __device__ unsigned long long g_lfc_stamps[1024 * 8];
 #define LFC_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) g_lfc_stamps[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+// ... and every wave its own: [block][wave][16]
+__device__ unsigned long long g_lfc_wstamps[1024 * 16 * 16];
+#define LFC_WSTAMP(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 1024) g_lfc_wstamps[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 16 + (i)] = wall_clock64(); } while (0)
 #else
 #define LFC_STAMP(i) do { } while (0)
+#define LFC_WSTAMP(i) do { } while (0)
 #endif
 typedef uint32_t v16u __attribute__((ext_vector_type(16)));
 // Both loads AND their wait in one statement, early-clobber outputs: the compiler can neither place `lo` over the
@@ -1732,10 +1736,14 @@ __device__ __forceinline__ void park_word(int &lo, int &hi, uint64_t word, int i
 // one layer over the block's cnt images: in / out = global maps [image][16] words (in: wave-uniform pointer)
 template <int KW>
 __device__ __forceinline__ void lfc_block_layer_s(const uint32_t *__restrict__ rows, int neuron, const uint64_t *in, uint64_t *out, int cnt,
-                                                  int wave, int lane, uint32_t &t) {
+                                                  int wave, int lane, uint32_t &t, int stamp = 0) {
   uint32_t wl[KW], wh[KW];
   int nt;
   lfc_row_regs<KW>(rows, neuron, wl, wh, nt);
+#ifdef BNN_LFC_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  LFC_WSTAMP(stamp);
+#endif
   v16u a_lo, a_hi;
   for (int base = 0; base < cnt; base += 64) {
     const int m = __builtin_amdgcn_readfirstlane(min(64, cnt - base));
@@ -1747,9 +1755,13 @@ __device__ __forceinline__ void lfc_block_layer_s(const uint32_t *__restrict__ r
     for (int i = 0; i < m; i++) {
       sload_image(in + (size_t)(base + i) * 16, a_lo, a_hi);
       park_word(lo, hi, __ballot(lfc_neuron_s<KW>(wl, wh, nt, a_lo, a_hi, t) < 0), i);
+#ifdef BNN_LFC_STAMPS
+      if (base == 0 && i == 0) LFC_WSTAMP(stamp + 1);
+#endif
     }
     if (lane < m) out[(size_t)(base + lane) * 16 + wave] = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
   }
+  LFC_WSTAMP(stamp + 2);
 }
 
 // all waves' stores of a layer are in L2, and no stale line of the map is left in the scalar cache
@@ -1772,6 +1784,7 @@ __global__ __launch_bounds__(1024, 2) void k_lfc_block_s(const uint8_t *__restri
   uint64_t *A = gA + (size_t)img0 * 16, *B = gB + (size_t)img0 * 16;
   uint32_t t = chain_temp();
   LFC_STAMP(0);
+  LFC_WSTAMP(0);
   // binarizeAndPack into A: one lane per output word (words 13..15 of an image are never read by layer 0)
   for (int idx = tid; idx < cnt * 16; idx += 1024) {
     const int i = idx >> 4, k = idx & 15;
@@ -1787,18 +1800,23 @@ __global__ __launch_bounds__(1024, 2) void k_lfc_block_s(const uint8_t *__restri
     }
     A[idx] = word;
   }
+  LFC_WSTAMP(1);
   lfc_block_handoff();
   LFC_STAMP(1);
-  lfc_block_layer_s<13>(r0, tid, A, B, cnt, wave, lane, t);
+  LFC_WSTAMP(2);
+  lfc_block_layer_s<13>(r0, tid, A, B, cnt, wave, lane, t, 3);
   LFC_STAMP(2);
   lfc_block_handoff();
   LFC_STAMP(3);
-  lfc_block_layer_s<16>(r1, tid, B, A, cnt, wave, lane, t);
+  LFC_WSTAMP(6);
+  lfc_block_layer_s<16>(r1, tid, B, A, cnt, wave, lane, t, 7);
   lfc_block_handoff();
   LFC_STAMP(4);
-  lfc_block_layer_s<16>(r2, tid, A, B, cnt, wave, lane, t);
+  LFC_WSTAMP(10);
+  lfc_block_layer_s<16>(r2, tid, A, B, cnt, wave, lane, t, 11);
   lfc_block_handoff();
   LFC_STAMP(5);
+  LFC_WSTAMP(14);
   {  // layer 3 (64 neurons: neuron = lane in every wave) + decode: the waves share out the images
     uint32_t wl[16], wh[16];
     int nt;
@@ -1817,11 +1835,13 @@ __global__ __launch_bounds__(1024, 2) void k_lfc_block_s(const uint8_t *__restri
     }
   }
   LFC_STAMP(6);
+  LFC_WSTAMP(15);
 }
 
 #ifdef BNN_LFC_STAMPS
 }  // namespace
 hipError_t lfc_stamps_read(unsigned long long *dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_lfc_stamps), sizeof(g_lfc_stamps)); }
+hipError_t lfc_wstamps_read(unsigned long long *dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_lfc_wstamps), sizeof(g_lfc_wstamps)); }
 namespace {
 #endif
 
@@ -1850,11 +1870,12 @@ inline long long lfc_block_max() {
   return v;
 }
 
-// images: from here on layer 0 runs in its LDS-staged tile form (k_conv0_tile); BNN_MI355X_L0_TILE_MIN overrides
+// images: from here on layer 0 runs in its LDS-staged tile form (k_conv0_tile) -- measured (tools/stage_times.py): 2 048
+// images 28.6 vs 18.2 us for the lane-per-pixel form, 8 192 44.7 vs 47.0, 131 072 516 vs 785; BNN_MI355X_L0_TILE_MIN overrides
 inline long long l0_tile_min() {
   static const long long v = [] {
     const char *e = std::getenv("BNN_MI355X_L0_TILE_MIN");
-    return e ? std::atoll(e) : 2048LL;
+    return e ? std::atoll(e) : 8192LL;
   }();
   return v;
 }

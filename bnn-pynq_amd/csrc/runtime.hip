@@ -17,9 +17,12 @@
 
 #include <fcntl.h>
 #include <sys/stat.h>
+#include <sched.h>
 #include <unistd.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -49,6 +52,10 @@ namespace bnn {
 namespace {
 
 constexpr int kMaxChunk = 131072;  // images per pass through the stages
+// Events that only TIME device work: a device-scope release at the record point instead of a flush to system scope
+// ("useful to obtain more precise timings of commands between events", hip_runtime_api.h).  Nothing on the host reads
+// results on the strength of these events: every entry point fetches them with a copy + stream synchronisation.
+constexpr unsigned kTimeEventFlags = hipEventReleaseToDevice;
 constexpr int kHostChunk = 32768;  // host-buffer / file path: H2D of chunk i+1 overlaps the stages of chunk i (largest chunk)
 constexpr int kHeadChunk = 2048;   // ... the first chunk: what the stages wait for before anything runs
 constexpr int kTailChunk = 4096;   // ... the last chunk: whose stages run after the last byte has arrived
@@ -140,6 +147,8 @@ struct Runtime {
   size_t file_cap = 0;
   std::unique_ptr<uint8_t[]> h_file[2];
   uint8_t *d_file[2] = {nullptr, nullptr};
+  size_t d_rec_cap = 0;  // feeder path: capacity of d_rec[] (records as they lie on disk, label bytes included)
+  uint8_t *d_rec[2] = {nullptr, nullptr};
   hipEvent_t file_sent[2] = {nullptr, nullptr};
   uint8_t *d_all = nullptr;  // a whole input file's images, resident (fault campaigns)
   size_t all_cap = 0;
@@ -236,7 +245,7 @@ int upload_blob() {
 
 void free_workspace() {
   Runtime &r = rt();
-  if (r.cap == 0 && r.stage_cap == 0 && r.res_cap == 0 && !r.d_pp_src && !r.d_pp_rec && !r.file_cap && !r.all_cap) return;
+  if (r.cap == 0 && r.stage_cap == 0 && r.res_cap == 0 && !r.d_pp_src && !r.d_pp_rec && !r.file_cap && !r.all_cap && !r.d_rec_cap) return;
   if (r.device >= 0) (void)hipSetDevice(r.device);
   (void)hipDeviceSynchronize();
   (void)hipFree(r.buf0); (void)hipFree(r.buf1); (void)hipFree(r.d_images[0]); (void)hipFree(r.d_images[1]);
@@ -250,6 +259,9 @@ void free_workspace() {
   r.all_cap = 0;
   (void)hipFree(r.d_file[0]); (void)hipFree(r.d_file[1]);
   r.d_file[0] = r.d_file[1] = nullptr;
+  (void)hipFree(r.d_rec[0]); (void)hipFree(r.d_rec[1]);
+  r.d_rec[0] = r.d_rec[1] = nullptr;
+  r.d_rec_cap = 0;
   r.h_file[0].reset(); r.h_file[1].reset();
   r.file_cap = 0;
   (void)hipFree(r.d_pp_src); (void)hipFree(r.d_pp_tmp); (void)hipFree(r.d_pp_rec); (void)hipFree(r.d_pp_coef);
@@ -387,6 +399,208 @@ bool ready() {
   return true;
 }
 
+// ---- host data -> HBM through a ring of pinned pieces --------------------------------------------------
+// hipMemcpyAsync from PAGEABLE memory is a single-threaded copy into the runtime's own pinned staging plus the DMA
+// (measured: 34 GB/s, 11.8 ms for 131 072 CIFAR images -- more than the 10.7 ms their stages take), and a file read
+// with pread() into a pageable chunk first pays a second CPU copy (27 GB/s with 8 reader threads).  For calls of
+// kFeederMinBytes and more, worker threads fill 4 MB pinned pieces -- memcpy from the caller's buffer, or pread()
+// straight from the page cache -- and the calling thread, the only one that talks to HIP, sends each piece with an
+// asynchronous DMA as soon as it is full: one CPU copy per byte, spread over the cores this process may use.
+constexpr size_t kFeederMinBytes = 24u << 20;
+int usable_cpus() {
+  int n = 0;
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+  if (n <= 0) n = (int)std::thread::hardware_concurrency();
+  if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {  // a container's CPU quota
+    long long quota = 0, period = 0;
+    char q[32] = {0};
+    if (std::fscanf(f, "%31s %lld", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0) {
+      quota = std::atoll(q);
+      const int lim = (int)(quota / period);
+      if (lim >= 1 && lim < n) n = lim;
+    }
+    std::fclose(f);
+  }
+  return n > 0 ? n : 1;
+}
+
+struct Feeder {
+  static constexpr int kSlots = 16;
+  static constexpr size_t kSlotBytes = 4u << 20;
+  struct Piece { int chunk; size_t off_in_chunk, src_off, bytes; bool last_of_chunk; };
+  uint8_t *ring = nullptr;  // kSlots x kSlotBytes, pinned
+  hipEvent_t sent[kSlots] = {};
+  std::vector<std::thread> workers;
+  std::mutex mu;
+  std::condition_variable cv_job, cv_done;
+  bool quit = false;
+  uint64_t job_id = 0;
+  // the job in flight
+  const std::vector<Piece> *pieces = nullptr;
+  const uint8_t *mem = nullptr;  // source: host memory ...
+  int fd = -1;                   // ... or a file
+  std::atomic<size_t> next{0}, released{0};
+  std::unique_ptr<std::atomic<uint8_t>[]> filled;  // per piece: 0 not yet, 1 filled, 2 failed
+  size_t filled_cap = 0;
+  std::atomic<bool> abort{false};
+  int active = 0;  // workers that have not yet left the current job (under mu)
+
+  bool fill(const Piece &pc, uint8_t *dst) const {
+    if (mem) { std::memcpy(dst, mem + pc.src_off, pc.bytes); return true; }
+    size_t done = 0;
+    while (done < pc.bytes) {
+      const ssize_t got = ::pread(fd, dst + done, pc.bytes - done, (off_t)(pc.src_off + done));
+      if (got <= 0) return false;
+      done += (size_t)got;
+    }
+    return true;
+  }
+  void worker() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_job.wait(lk, [&] { return quit || job_id != seen; });
+        if (quit) return;
+        seen = job_id;
+      }
+      const size_t np = pieces->size();
+      for (;;) {
+        const size_t p = next.fetch_add(1, std::memory_order_relaxed);
+        if (p >= np) break;
+        while (!abort.load(std::memory_order_relaxed) && p >= released.load(std::memory_order_acquire) + kSlots) std::this_thread::yield();
+        const bool ok = !abort.load(std::memory_order_relaxed) && fill((*pieces)[p], ring + (p % kSlots) * kSlotBytes);
+        filled[p].store(ok ? 1 : 2, std::memory_order_release);
+      }
+      std::lock_guard<std::mutex> lk(mu);
+      if (--active == 0) cv_done.notify_all();
+    }
+  }
+  // pinned ring, events and worker threads: once per process (the threads sleep between jobs)
+  int init() {
+    if (ring) return 0;
+    if (hipHostMalloc(reinterpret_cast<void **>(&ring), kSlots * kSlotBytes, hipHostMallocDefault) != hipSuccess) { ring = nullptr; return -1; }
+    for (auto &e : sent)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -1;
+    int nt = usable_cpus() - 2;  // leave a core to the calling thread and one to the driver's
+    if (const char *e = std::getenv("BNN_MI355X_FEEDER_THREADS")) nt = std::atoi(e);
+    nt = nt < 1 ? 1 : (nt > 14 ? 14 : nt);
+    for (int i = 0; i < nt; i++) workers.emplace_back([this] { worker(); });
+    return 0;
+  }
+  void begin(const std::vector<Piece> &pcs, const uint8_t *m, int f) {
+    if (pcs.size() > filled_cap) {
+      filled.reset(new std::atomic<uint8_t>[pcs.size()]);
+      filled_cap = pcs.size();
+    }
+    for (size_t i = 0; i < pcs.size(); i++) filled[i].store(0, std::memory_order_relaxed);
+    next = 0; released = 0; abort = false;
+    std::lock_guard<std::mutex> lk(mu);
+    pieces = &pcs; mem = m; fd = f;
+    active = (int)workers.size();
+    job_id++;
+    cv_job.notify_all();
+  }
+  // every worker has left the job: its description may go out of scope
+  void end() {
+    abort = true;  // (a no-op after a complete run: nothing is left to claim)
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [&] { return active == 0; });
+  }
+  ~Feeder() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      quit = true;
+      cv_job.notify_all();
+    }
+    for (auto &t : workers) t.join();
+  }
+};
+Feeder &feeder() {
+  static Feeder f;
+  return f;
+}
+bool use_feeder(size_t bytes) {
+  static const bool off = std::getenv("BNN_MI355X_NO_FEEDER") != nullptr;
+  return !off && bytes >= kFeederMinBytes;
+}
+
+// n images from host memory (fd < 0) or from an open file, cut by `plan`, through the pinned ring into the two HBM
+// chunk buffers; consume(c, base, m, slot) enqueues chunk c's stages on r.stream once its bytes (label bytes
+// stripped: rec > isz) are in r.d_images[slot] and r.stream has been made to wait for them.
+template <typename Consume>
+int feed_chunks(const uint8_t *mem, int fd, size_t first, size_t rec, size_t skip, const std::vector<int> &plan, Consume consume) {
+  Runtime &r = rt();
+  Feeder &F = feeder();
+  if (F.init()) return fail("pinned staging ring: allocation failed");
+  const int nchunks = (int)plan.size() - 1;
+  if (skip) {  // records go to HBM as they lie on disk; k_strip_records drops the label bytes
+    const size_t need = (size_t)largest_chunk(plan) * rec + 256;
+    if (need > r.d_rec_cap) {
+      HIP_OK(hipDeviceSynchronize());
+      for (int i = 0; i < 2; i++) {
+        (void)hipFree(r.d_rec[i]);
+        r.d_rec[i] = nullptr;
+      }
+      r.d_rec_cap = 0;
+      for (int i = 0; i < 2; i++) HIP_OK(hipMalloc(reinterpret_cast<void **>(&r.d_rec[i]), need));
+      r.d_rec_cap = need;
+    }
+  }
+  std::vector<Feeder::Piece> pieces;
+  for (int c = 0; c < nchunks; c++) {
+    const size_t bytes = (size_t)(plan[c + 1] - plan[c]) * rec, src0 = first + (size_t)plan[c] * rec;
+    for (size_t o = 0; o < bytes; o += Feeder::kSlotBytes) {
+      const size_t b = bytes - o < Feeder::kSlotBytes ? bytes - o : Feeder::kSlotBytes;
+      pieces.push_back({c, o, src0 + o, b, o + b == bytes});
+    }
+  }
+  F.begin(pieces, mem, fd);
+  struct End {
+    Feeder &f;
+    ~End() { f.end(); }
+  } end_guard{F};
+  size_t issued = 0, released = 0;
+  auto release_done = [&]() {  // pieces whose DMA has finished: their ring slots may be refilled
+    while (released < issued && hipEventQuery(F.sent[released % Feeder::kSlots]) == hipSuccess) released++;
+    F.released.store(released, std::memory_order_release);
+  };
+  for (size_t p = 0; p < pieces.size(); p++) {
+    const Feeder::Piece &pc = pieces[p];
+    const int c = pc.chunk, slot = c & 1;
+    uint8_t st;
+    while ((st = F.filled[p].load(std::memory_order_acquire)) == 0) {
+      release_done();
+      std::this_thread::yield();
+    }
+    if (st != 1) {
+      F.abort = true;
+      return fail("input file: read error");
+    }
+    uint8_t *chunk_dst = skip ? r.d_rec[slot] : r.d_images[slot];
+    // the chunk buffer of two chunks ago: its stages (no label bytes) / its strip kernel (same stream: in order) are done
+    if (!skip && pc.off_in_chunk == 0 && c >= 2) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));
+    HIP_OK(hipMemcpyAsync(chunk_dst + pc.off_in_chunk, F.ring + (p % Feeder::kSlots) * Feeder::kSlotBytes, pc.bytes, hipMemcpyHostToDevice,
+                          r.copy_stream));
+    HIP_OK(hipEventRecord(F.sent[p % Feeder::kSlots], r.copy_stream));
+    issued = p + 1;
+    release_done();
+    if (!pc.last_of_chunk) continue;
+    const int base = plan[c], m = plan[c + 1] - plan[c];
+    if (skip) {
+      if (c >= 2) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));  // d_images[slot] free again
+      const hipError_t e = launch_strip_records(r.d_rec[slot], (int)rec, (int)skip, r.d_images[slot], m, r.copy_stream);
+      if (e != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(e));
+    }
+    HIP_OK(hipEventRecord(r.copied[slot], r.copy_stream));
+    HIP_OK(hipStreamWaitEvent(r.stream, r.copied[slot], 0));
+    if (consume(c, base, m, slot)) return -1;
+    HIP_OK(hipEventRecord(r.consumed[slot], r.stream));
+  }
+  return 0;
+}
+
 // n host images -> any of classes / scores / words (host arrays), chunked.
 // usec: device time of the compute stages only, per image (the reference times
 // the accelerator call alone, foldedmv-offload.h:389-392).
@@ -404,7 +618,7 @@ int infer_host(const uint8_t *imgs, int n, int ncls, int32_t *classes, int16_t *
   if (reserve(chunk) || reserve_host(chunk, (size_t)n)) return -1;
   while ((int)r.time_events.size() < 2 * nchunks) {
     hipEvent_t e;
-    HIP_OK(hipEventCreate(&e));
+    HIP_OK(hipEventCreateWithFlags(&e, kTimeEventFlags));
     r.time_events.push_back(e);
   }
   DrainOnFailure drain;
@@ -412,7 +626,13 @@ int infer_host(const uint8_t *imgs, int n, int ncls, int32_t *classes, int16_t *
   // Two staging buffers: the copy engine fills one while the stages consume the other.  Results of
   // every chunk stay in HBM and come back in one transfer at the end (a D2H into pageable memory
   // would otherwise make the host wait for each chunk's kernels before it can queue the next copy).
-  for (int c = 0; c < nchunks; c++) {
+  auto stages = [&](int c, int base, int m, int slot) {
+    return enqueue(r.d_images[slot], m, ncls, classes ? r.d_classes + base : nullptr, want_scores ? r.d_scores + (size_t)base * 64 : nullptr,
+                   r.d_words + base, r.stream, r.time_events[2 * c], r.time_events[2 * c + 1]);
+  };
+  const bool fed = nchunks > 1 && use_feeder((size_t)n * isz);  // large call: pinned ring, filled by worker threads (above)
+  if (fed && feed_chunks(imgs, -1, 0, isz, 0, plan, stages)) return -1;
+  for (int c = 0; c < (fed ? 0 : nchunks); c++) {
     const int base = plan[c], m = plan[c + 1] - plan[c], slot = c & 1;
     if (nchunks == 1) {  // nothing to overlap: stay on one stream (fewer driver round trips for small calls)
       HIP_OK(hipMemcpyAsync(r.d_images[slot], imgs, (size_t)m * isz, hipMemcpyHostToDevice, r.stream));
@@ -422,9 +642,7 @@ int infer_host(const uint8_t *imgs, int n, int ncls, int32_t *classes, int16_t *
       HIP_OK(hipEventRecord(r.copied[slot], r.copy_stream));
       HIP_OK(hipStreamWaitEvent(r.stream, r.copied[slot], 0));
     }
-    if (enqueue(r.d_images[slot], m, ncls, classes ? r.d_classes + base : nullptr, want_scores ? r.d_scores + (size_t)base * 64 : nullptr,
-                r.d_words + base, r.stream, r.time_events[2 * c], r.time_events[2 * c + 1]))
-      return -1;
+    if (stages(c, base, m, slot)) return -1;
     if (nchunks > 1) HIP_OK(hipEventRecord(r.consumed[slot], r.stream));
   }
   if (classes) HIP_OK(hipMemcpyAsync(classes, r.d_classes, (size_t)n * 4, hipMemcpyDeviceToHost, r.stream));
@@ -453,6 +671,7 @@ int warm_up() {
   const int big = 8192;
   const size_t isz = (size_t)r.spec.image_bytes();
   if (reserve(big) || reserve_host(big, (size_t)big)) return -1;
+  if (!std::getenv("BNN_MI355X_NO_FEEDER") && feeder().init()) return fail("pinned staging ring: allocation failed");
   HIP_OK(hipMemsetAsync(r.d_images[0], 0, (size_t)big * isz, r.stream));
   for (int n : {1, 2, 300, 600, 1100, 2500, 5000, big})  // one batch size inside every band of the dispatch policy
     if (enqueue(r.d_images[0], n, 10, r.d_classes, r.spec.is_cnv ? r.d_scores : nullptr, r.d_words, r.stream)) return -1;
@@ -462,7 +681,7 @@ int warm_up() {
   }
   while (r.time_events.size() < 2) {
     hipEvent_t e;
-    HIP_OK(hipEventCreate(&e));
+    HIP_OK(hipEventCreateWithFlags(&e, kTimeEventFlags));
     r.time_events.push_back(e);
   }
   HIP_OK(hipEventRecord(r.time_events[0], r.stream));
@@ -636,19 +855,19 @@ int infer_file(const ImageFile &f, int n, int ncls, int32_t *classes, int16_t *s
   if (reserve(chunk) || reserve_host(chunk, (size_t)n)) return -1;
   while ((int)r.time_events.size() < 2 * nchunks) {
     hipEvent_t e;
-    HIP_OK(hipEventCreate(&e));
+    HIP_OK(hipEventCreateWithFlags(&e, kTimeEventFlags));
     r.time_events.push_back(e);
   }
   DrainOnFailure drain;
   const bool want_scores = scores && r.spec.is_cnv;
-  const int rc = stream_file(
-      f, n, true, [&](int, int slot) { return r.d_images[slot]; },
-      [&](int c, int base, int m, int slot) {
-        if (enqueue(r.d_images[slot], m, ncls, classes ? r.d_classes + base : nullptr, want_scores ? r.d_scores + (size_t)base * 64 : nullptr,
-                    r.d_words + base, r.stream, r.time_events[2 * c], r.time_events[2 * c + 1]))
-          return -1;
-        return 0;
-      });
+  auto stages = [&](int c, int base, int m, int slot) {
+    return enqueue(r.d_images[slot], m, ncls, classes ? r.d_classes + base : nullptr, want_scores ? r.d_scores + (size_t)base * 64 : nullptr,
+                   r.d_words + base, r.stream, r.time_events[2 * c], r.time_events[2 * c + 1]);
+  };
+  // large file: worker threads pread() it into the pinned ring piece by piece (feed_chunks); small: one or a few chunks
+  // through a pageable host chunk (stream_file)
+  const int rc = (nchunks > 1 && use_feeder((size_t)n * f.rec)) ? feed_chunks(nullptr, f.fd, f.first, f.rec, f.skip, plan, stages)
+                                                              : stream_file(f, n, true, [&](int, int slot) { return r.d_images[slot]; }, stages);
   if (rc) return -1;
   if (classes) HIP_OK(hipMemcpyAsync(classes, r.d_classes, (size_t)n * 4, hipMemcpyDeviceToHost, r.stream));
   if (want_scores) HIP_OK(hipMemcpyAsync(scores, r.d_scores, (size_t)n * 128, hipMemcpyDeviceToHost, r.stream));
@@ -730,7 +949,7 @@ int *classify_host(const uint8_t *imgs, int n, int ncls, float *usec, int enable
 }  // namespace bnn
 
 #ifdef BNN_LFC_STAMPS
-namespace bnn { hipError_t lfc_stamps_read(unsigned long long *dst); }
+namespace bnn { hipError_t lfc_stamps_read(unsigned long long *dst); hipError_t lfc_wstamps_read(unsigned long long *dst); }
 #endif
 using namespace bnn;
 
@@ -843,7 +1062,7 @@ int *inference_multiple_with_faults(const char *path, int number_class, int *ima
     // bytes each, and an event pair per run would cost more than they do
     while (r.time_events.size() < 2) {
       hipEvent_t e;
-      HIP_OK(hipEventCreate(&e));
+      HIP_OK(hipEventCreateWithFlags(&e, kTimeEventFlags));
       r.time_events.push_back(e);
     }
     HIP_OK(hipEventRecord(r.time_events[0], r.stream));
@@ -1017,6 +1236,11 @@ int bnn_mi355x_reserve(int max_images) { return ready() ? reserve(max_images) : 
 int bnn_mi355x_debug_lfc_stamps(unsigned long long *dst) {
   if (hipDeviceSynchronize() != hipSuccess) return -1;
   return bnn::lfc_stamps_read(dst) == hipSuccess ? 0 : -1;
+}
+// ... and 1024 blocks x 16 waves x 16 stamps
+int bnn_mi355x_debug_lfc_wstamps(unsigned long long *dst) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  return bnn::lfc_wstamps_read(dst) == hipSuccess ? 0 : -1;
 }
 #endif
 

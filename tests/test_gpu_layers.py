@@ -158,12 +158,12 @@ def test_layer0_tile_form_is_bit_exact(tmp_path):
 
 @pytest.mark.parametrize("network", ["cnvW1A1", "cnvW1A2", "cnvW2A2"])
 def test_layer0_forms_agree_across_the_policy_edge(network):
-    """2047 images run layer 0 with a lane per pixel (k_conv0_mfma), 2048 and more from LDS-staged images
-    (k_conv0_tile, blocks of 8 images; 2051 leaves a block of 3): stage-0 bits of the same images equal in both"""
+    """8191 images run layer 0 with a lane per pixel (k_conv0_mfma), 8192 and more from LDS-staged images
+    (k_conv0_tile, blocks of 8 images; 8195 leaves a block of 3): stage-0 bits of the same images equal in both"""
     L = gl.load(network)
     L.load_parameters(gl.param_dir("cifar10", network).encode())
-    imgs = np.random.default_rng(77).integers(0, 256, (2051, 3072), dtype=np.uint8)
+    imgs = np.random.default_rng(77).integers(0, 256, (8195, 3072), dtype=np.uint8)
     tile = stage_output(L, imgs, 0)
-    pixel = stage_output(L, imgs[:2047], 0)
-    assert (tile[:2047] == pixel).all()
-    assert (stage_output(L, imgs[2040:], 0) == tile[2040:]).all()       # the ragged block's images, as a small batch
+    pixel = stage_output(L, imgs[:8191], 0)
+    assert (tile[:8191] == pixel).all()
+    assert (stage_output(L, imgs[8184:], 0) == tile[8184:]).all()       # the ragged block's images, as a small batch

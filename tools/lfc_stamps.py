@@ -46,3 +46,28 @@ life = t[:, 6] - t[:, 0]
 print("  block lifetime     min %6.2f  median %6.2f  max %6.2f us;  first entry -> last exit %.2f us" % (life.min(), np.median(life), life.max(), t[:, 6].max()))
 order = np.argsort(t[:, 0])
 print("  entry time by block id (every 50th):", " ".join("%d:%.1f" % (b, t[b, 0]) for b in range(0, blocks, 50)))
+
+# ---- per-wave stamps: [block][wave][16]
+L.bnn_mi355x_debug_lfc_wstamps.argtypes = [C.c_void_p]
+ws = np.zeros((1024, 16, 16), np.uint64)
+assert L.bnn_mi355x_debug_lfc_wstamps(ws.ctypes.data) == 0
+w = (ws[:blocks].astype(np.int64) - s[:, 0].min()) / 100.0
+wn = ["entry", "prologue done", "handoff0 done", "L0 rows in", "L0 image 0 done", "L0 loop done", "L0 handoff done", "L1 rows in", "L1 image 0 done",
+      "L1 loop done", "L1 handoff done", "L2 rows in", "L2 image 0 done", "L2 loop done", "L2 handoff done", "exit"]
+print("per-wave phase lengths over all %d waves (us): min / p50 / p90 / p99 / max" % (blocks * 16))
+for i in range(1, 16):
+    d = (w[:, :, i] - w[:, :, i - 1]).reshape(-1)
+    print("  %-18s %6.2f %6.2f %6.2f %6.2f %6.2f" % (wn[i], d.min(), np.percentile(d, 50), np.percentile(d, 90), np.percentile(d, 99), d.max()))
+ex = t[:, 6]
+print("exit time percentiles over blocks: p50 %.1f p75 %.1f p90 %.1f p95 %.1f p99 %.1f max %.1f" % tuple(np.percentile(ex, q) for q in (50, 75, 90, 95, 99, 100)))
+late = np.argsort(-ex)[:8]
+print("eight latest blocks (id, id mod 8, exit):", " ".join("%d/%d/%.1f" % (b, b % 8, ex[b]) for b in late))
+print("blocks later than median + 5 us: %d; by id mod 8: %s" % ((ex > np.median(ex) + 5).sum(), np.bincount(np.nonzero(ex > np.median(ex) + 5)[0] % 8, minlength=8).tolist()))
+b = int(late[0])
+print("latest block %d, per wave (rows: waves 0..15; columns: the 16 stamps, us since first entry):" % b)
+for wv in range(16):
+    print("   w%-2d " % wv + " ".join("%6.1f" % x for x in w[b, wv]))
+b = int(np.argsort(ex)[len(ex) // 2])
+print("a median block %d:" % b)
+for wv in range(16):
+    print("   w%-2d " % wv + " ".join("%6.1f" % x for x in w[b, wv]))
