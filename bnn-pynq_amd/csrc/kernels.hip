@@ -1752,9 +1752,21 @@ __device__ __forceinline__ void lfc_block_layer_s(const uint32_t *__restrict__ r
     // block per CU; with 8 waves on the SIMD the other seven cover this wave's scalar load.  (Touching image i + 2
     // in the scalar cache ahead of time was measured: no gain -- and it would have been the only access outside
     // the block's own images.)
+    // The 16 waves of the block walk the chunk's images in ROTATED order (wave w starts at image w * m / 16): if they
+    // all asked for image i at the same time, each of them would sit out the full trip to L2 for every image (the map
+    // was just written: the scalar cache is cold) -- 0.5-0.8 us per image and wave, measured with per-wave clock stamps
+    // (profiles/r03_lfc_block_stamps.txt), which made the kernel latency-bound at 2/3 of the issue rate; rotated, an
+    // image is fetched once by whichever wave reaches it first and is a cache hit for the other fifteen.
+#ifdef BNN_LFC_NO_ROTATE  // A/B build only
+    const int rot = 0;
+#else
+    const int rot = (wave * m) >> 4;
+#endif
     for (int i = 0; i < m; i++) {
-      sload_image(in + (size_t)(base + i) * 16, a_lo, a_hi);
-      park_word(lo, hi, __ballot(lfc_neuron_s<KW>(wl, wh, nt, a_lo, a_hi, t) < 0), i);
+      int j = i + rot;
+      j = j >= m ? j - m : j;
+      sload_image(in + (size_t)(base + j) * 16, a_lo, a_hi);
+      park_word(lo, hi, __ballot(lfc_neuron_s<KW>(wl, wh, nt, a_lo, a_hi, t) < 0), j);
 #ifdef BNN_LFC_STAMPS
       if (base == 0 && i == 0) LFC_WSTAMP(stamp + 1);
 #endif
