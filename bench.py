@@ -177,9 +177,11 @@ def issue_floor_cycles(network):
     kind, prec = network[:3], network[3:]
     cyc = WORD_MACS[kind] * PAIRS_PER_WORD[prec] * PAIR_CYC_OF[prec]
     if kind == "cnv":
-        # layer 0 runs on the matrix pipe (v_mfma_i32_32x32x32_i8); what stays on the integer pipe is the
-        # tap gather + quantise (~105 instructions per pixel-lane) and one v_alignbit per neuron (64) + merges
-        cyc += 900 * 170 * SLOT_CYC
+        # layer 0 runs on the matrix pipe (k_conv0_tile); what stays on the integer pipe per 32-pixel tile and lane: one
+        # v_alignbit per result (32), one v_alignbyte per 3-tap run (5), shifts / merge / store and addressing (~13); 29
+        # tiles of 64 lanes per image, + quantising every input byte once (768 dwords x 7)
+        # (2-bit activations: a second threshold = 32 more results per tile and lane)
+        cyc += (29 * 64 * (50 + (32 if prec.endswith("A2") else 0)) + 768 * 7) * SLOT_CYC
     return cyc / 64.0                                # 64 lanes per wave instruction
 
 
@@ -416,7 +418,7 @@ def main():
     dev_ms = sum(per_stage)
     alg = ALG_BYTES["cnv" if is_cnv else "lfc"]
     achieved = alg * a.batch / (dev_ms * 1e-3) / 1e9
-    traffic, traffic_source = None, None
+    traffic, traffic_source, traffic_stages = None, None, None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf):
         try:
@@ -425,6 +427,11 @@ def main():
                               "two rocprofv3 --pmc passes (%s), scaled to this launch; not re-measured in this run" % t.get("source", "profiles/"))
             # measured HBM bytes per image (PMC passes, profiles/) x the images of one launch
             traffic = int((t["fetch_bytes_per_image_x2"] + t["write_bytes_per_image"]) * imgs_per_launch)
+            # per stage, in launch order: where the bytes above the 3 076 algorithmic ones go (the maps between the stages,
+            # each written once and read once: no fusion)
+            traffic_stages = {names[i] if i < len(names) else st["kernel"]: {"kernel": st["kernel"], "fetch_x2": st["fetch_bytes_per_image_x2"],
+                                                                              "write": st["write_bytes_per_image"]}
+                              for i, st in enumerate(t.get("stages", []))} or None
         except Exception:
             traffic = None
     # the dominant kernel on its own: bytes that one stage must move per image (input map + output map)
@@ -440,6 +447,7 @@ def main():
                          "frac": round(dom_alg * a.batch / (per_stage[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)})
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
+                "traffic_bytes_per_image_by_stage": traffic_stages,
                 "kernel": "all %d stages of one batch (dominant: %s, %.1f%% of device time)" % (
                     nst, names[dom], 100.0 * per_stage[dom] / dev_ms),
                 "algorithmic_bytes_per_image": alg, "images_per_launch": int(imgs_per_launch),
