@@ -792,23 +792,11 @@ __global__ __launch_bounds__(kBlock) void k_vec_x(const uint64_t *__restrict__ i
     }
   }
   uint32_t t = chain_temp();
-  // The four waves of a block walk the group's neurons in ROTATED order (wave w starts a quarter of the way on): a
-  // weight row is then pulled through the scalar cache by whichever wave reaches it first and is a hit for the
-  // other three, instead of all four sitting out the same miss at the same time (the FC layers consume a weight
-  // dword per pair, four times what the conv layers do: profiles/r02_sq_staged_lfcW1A1.json).
-#ifdef BNN_VEC_NO_ROTATE  // A/B build only
-  const int start = NPB - 1;
-#else
-  const int start = NPB - 1 - (NPB / 4) * __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-#endif
   for (int cg = bm.cg * gpb, cg_end = cg + gpb; cg < cg_end; cg++) {  // see k_conv0
     kptr32 w = (kptr32)(uintptr_t)(rows + (size_t)cg * NPB * ROW_DW);
     uint32_t b = 0;
-    for (int it = 0; it < NPB / 2; it++) {
-      const int c = (start - 2 * it) & (NPB - 1);  // odd: the pair (c, c - 1)
-      kptr32 r0 = w + (c - 1) * ROW_DW;
-      asm("" : "+s"(r0));  // an opaque base: both rows' dwords are then base + (positive) constant, which merge into s_load_dwordx8
-      kptr32 r1 = r0 + ROW_DW;
+    for (int c = NPB - 1; c >= 0; c -= 2) {
+      kptr32 r1 = w + c * ROW_DW, r0 = r1 - ROW_DW;
       int m1 = xpop_seed(r1[2], al[0], -(int)r1[0], t), m0 = xpop_seed(r0[2], al[0], -(int)r0[0], t);
       xpop(m1, r1[3], ah[0], t);
       xpop(m0, r0[3], ah[0], t);
@@ -822,9 +810,6 @@ __global__ __launch_bounds__(kBlock) void k_vec_x(const uint64_t *__restrict__ i
       b = shift_in_sign(b, m1);
       b = shift_in_sign(b, m0);
     }
-    // the shifts put neuron (start + 1 + p) mod NPB at bit p: rotate it home
-    if constexpr (NPB == 32) b = __builtin_amdgcn_alignbit(b, b, (31 - start) & 31);
-    else b = ((b << ((start + 1) & (NPB - 1))) | ((b & (uint32_t)((1u << NPB) - 1)) >> ((NPB - 1 - start) & (NPB - 1)))) & (uint32_t)((1u << NPB) - 1);
     if constexpr (POOL) {
       b |= __shfl_xor(b, 1, 64);
       b |= __shfl_xor(b, 2, 64);
