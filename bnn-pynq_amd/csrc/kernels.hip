@@ -1685,6 +1685,11 @@ __device__ unsigned long long g_lfc_wstamps[1024 * 16 * 16];
 #define LFC_STAMP(i) do { } while (0)
 #define LFC_WSTAMP(i) do { } while (0)
 #endif
+#ifdef BNN_LFC_NO_PRIO  // A/B build only
+#define LFC_PRIO(p) do { } while (0)
+#else
+#define LFC_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#endif
 typedef uint32_t v16u __attribute__((ext_vector_type(16)));
 // Both loads AND their wait in one statement, early-clobber outputs: the compiler can neither place `lo` over the
 // address pair the second load still reads, nor copy / spill the tuples between the loads and the wait.
@@ -1752,21 +1757,11 @@ __device__ __forceinline__ void lfc_block_layer_s(const uint32_t *__restrict__ r
     // block per CU; with 8 waves on the SIMD the other seven cover this wave's scalar load.  (Touching image i + 2
     // in the scalar cache ahead of time was measured: no gain -- and it would have been the only access outside
     // the block's own images.)
-    // The 16 waves of the block walk the chunk's images in ROTATED order (wave w starts at image w * m / 16): if they
-    // all asked for image i at the same time, each of them would sit out the full trip to L2 for every image (the map
-    // was just written: the scalar cache is cold) -- 0.5-0.8 us per image and wave, measured with per-wave clock stamps
-    // (profiles/r03_lfc_block_stamps.txt), which made the kernel latency-bound at 2/3 of the issue rate; rotated, an
-    // image is fetched once by whichever wave reaches it first and is a cache hit for the other fifteen.
-#ifdef BNN_LFC_NO_ROTATE  // A/B build only
-    const int rot = 0;
-#else
-    const int rot = (wave * m) >> 4;
-#endif
+    // (Walking the images in an order rotated per wave -- so that an image's scalar-cache miss is paid by one wave
+    // instead of all sixteen at once -- was measured: no change, 61.9 vs 61.6 us for 10 000 images.)
     for (int i = 0; i < m; i++) {
-      int j = i + rot;
-      j = j >= m ? j - m : j;
-      sload_image(in + (size_t)(base + j) * 16, a_lo, a_hi);
-      park_word(lo, hi, __ballot(lfc_neuron_s<KW>(wl, wh, nt, a_lo, a_hi, t) < 0), j);
+      sload_image(in + (size_t)(base + i) * 16, a_lo, a_hi);
+      park_word(lo, hi, __ballot(lfc_neuron_s<KW>(wl, wh, nt, a_lo, a_hi, t) < 0), i);
 #ifdef BNN_LFC_STAMPS
       if (base == 0 && i == 0) LFC_WSTAMP(stamp + 1);
 #endif
@@ -1816,19 +1811,28 @@ __global__ __launch_bounds__(1024, 2) void k_lfc_block_s(const uint8_t *__restri
   lfc_block_handoff();
   LFC_STAMP(1);
   LFC_WSTAMP(2);
+  // The SIMD's arbiter serves the OLDEST wave first.  With two blocks per CU that made the older block run three
+  // layers in 40 us while the younger one was still in its first, which then ran the rest alone at half the issue
+  // rate: 244 of 500 blocks finished at 40 us, the other 244 at 61 (per-wave clock stamps, profiles/r03_lfc_block_stamps.txt).
+  // So a wave's priority falls with the layer it is in: whichever block is behind goes first, the two stay within a
+  // layer of each other and the SIMDs have eight waves to choose from until the end.
+  LFC_PRIO(3);
   lfc_block_layer_s<13>(r0, tid, A, B, cnt, wave, lane, t, 3);
   LFC_STAMP(2);
   lfc_block_handoff();
   LFC_STAMP(3);
   LFC_WSTAMP(6);
+  LFC_PRIO(2);
   lfc_block_layer_s<16>(r1, tid, B, A, cnt, wave, lane, t, 7);
   lfc_block_handoff();
   LFC_STAMP(4);
   LFC_WSTAMP(10);
+  LFC_PRIO(1);
   lfc_block_layer_s<16>(r2, tid, A, B, cnt, wave, lane, t, 11);
   lfc_block_handoff();
   LFC_STAMP(5);
   LFC_WSTAMP(14);
+  LFC_PRIO(0);
   {  // layer 3 (64 neurons: neuron = lane in every wave) + decode: the waves share out the images
     uint32_t wl[16], wh[16];
     int nt;
