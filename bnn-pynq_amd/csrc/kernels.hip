@@ -1691,6 +1691,20 @@ __device__ unsigned long long g_lfc_wstamps[1024 * 16 * 16];
 #define LFC_PRIO(p) __builtin_amdgcn_s_setprio(p)
 #endif
 typedef uint32_t v16u __attribute__((ext_vector_type(16)));
+// row `n` of a layer with KW input words into the first KW entries of (wl, wh)
+template <int KW>
+__device__ __forceinline__ void lfc_row_regs16(const uint32_t *__restrict__ rows, int n, uint32_t (&wl)[16], uint32_t (&wh)[16], int &nt) {
+  constexpr int ROW_DW = 2 + 2 * KW;
+  const uint32_t *__restrict__ r = rows + (size_t)n * ROW_DW;
+  nt = -(int)r[0];
+  const uint2 *__restrict__ p = reinterpret_cast<const uint2 *>(r + 2);
+#pragma unroll
+  for (int k = 0; k < KW; k++) {
+    const uint2 v = p[k];
+    wl[k] = v.x;
+    wh[k] = v.y;
+  }
+}
 // Both loads AND their wait in one statement, early-clobber outputs: the compiler can neither place `lo` over the
 // address pair the second load still reads, nor copy / spill the tuples between the loads and the wait.
 __device__ __forceinline__ void sload_image(const uint64_t *p, v16u &lo, v16u &hi) {  // p: wave-uniform
@@ -1699,8 +1713,8 @@ __device__ __forceinline__ void sload_image(const uint64_t *p, v16u &lo, v16u &h
 // m - t of this thread's neuron for one image (its 32 dwords in SGPRs).  (Two neurons per thread -- 4 * KW
 // pairs per scalar-load wait, 512-thread blocks -- was measured too: 3 % faster at 131 072 images, 10 % slower at
 // 10 000, where this kernel is used.)
-template <int KW>
-__device__ __forceinline__ int lfc_neuron_s(const uint32_t (&wl)[KW], const uint32_t (&wh)[KW], int nt, const v16u &lo, const v16u &hi,
+template <int KW, int N = KW>
+__device__ __forceinline__ int lfc_neuron_s(const uint32_t (&wl)[N], const uint32_t (&wh)[N], int nt, const v16u &lo, const v16u &hi,
                                             uint32_t &t) {
   auto word = [&](int d) { return d < 16 ? lo[d] : hi[d - 16]; };
   int m;
@@ -1739,16 +1753,16 @@ __device__ __forceinline__ void park_word(int &lo, int &hi, uint64_t word, int i
 #pragma clang diagnostic pop
 
 // one layer over the block's cnt images: in / out = global maps [image][16] words (in: wave-uniform pointer)
-template <int KW>
-__device__ __forceinline__ void lfc_block_layer_s(const uint32_t *__restrict__ rows, int neuron, const uint64_t *in, uint64_t *out, int cnt,
-                                                  int wave, int lane, uint32_t &t, int stamp = 0) {
-  uint32_t wl[KW], wh[KW];
-  int nt;
-  lfc_row_regs<KW>(rows, neuron, wl, wh, nt);
-#ifdef BNN_LFC_STAMPS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+// The weight row of the layer is in (wl, wh, nt) on entry; on exit the row of the NEXT layer (NKW words, 0: none) has
+// been requested into the same registers.  (Written behind this layer's last pair, in front of the hand-off; the
+// compiler sinks the loads behind the barrier all the same -- and rightly so: the wave that arrives last, the one
+// the barrier waits for, could not have issued them any earlier, its registers hold the current row until then.  Only
+// layer 0's row, requested at kernel entry, has its trip to L2 -- 1.3-2 us, per-wave clock stamps -- hidden.)
+template <int KW, int NKW, int MIDPRIO = -1>
+__device__ __forceinline__ void lfc_block_layer_s(const uint32_t *__restrict__ next_rows, int next_neuron, uint32_t (&wl)[16], uint32_t (&wh)[16],
+                                                  int &nt, const uint64_t *in, uint64_t *out, int cnt, int wave, int lane, uint32_t &t,
+                                                  int stamp = 0, int switch_at = -1) {
   LFC_WSTAMP(stamp);
-#endif
   v16u a_lo, a_hi;
   for (int base = 0; base < cnt; base += 64) {
     const int m = __builtin_amdgcn_readfirstlane(min(64, cnt - base));
@@ -1760,14 +1774,20 @@ __device__ __forceinline__ void lfc_block_layer_s(const uint32_t *__restrict__ r
     // (Walking the images in an order rotated per wave -- so that an image's scalar-cache miss is paid by one wave
     // instead of all sixteen at once -- was measured: no change, 61.9 vs 61.6 us for 10 000 images.)
     for (int i = 0; i < m; i++) {
+#ifdef BNN_LFC_PRIO_QUARTER  // A/B build: the priority steps fall INSIDE the layers (at 3/4, 1/2, 1/4 of layers 0, 1, 2)
+      if constexpr (MIDPRIO >= 0) {
+        if (base + i == switch_at) LFC_PRIO(MIDPRIO);
+      }
+#endif
       sload_image(in + (size_t)(base + i) * 16, a_lo, a_hi);
-      park_word(lo, hi, __ballot(lfc_neuron_s<KW>(wl, wh, nt, a_lo, a_hi, t) < 0), i);
+      park_word(lo, hi, __ballot(lfc_neuron_s<KW, 16>(wl, wh, nt, a_lo, a_hi, t) < 0), i);
 #ifdef BNN_LFC_STAMPS
       if (base == 0 && i == 0) LFC_WSTAMP(stamp + 1);
 #endif
     }
     if (lane < m) out[(size_t)(base + lane) * 16 + wave] = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
   }
+  if constexpr (NKW > 0) lfc_row_regs16<NKW>(next_rows, next_neuron, wl, wh, nt);
   LFC_WSTAMP(stamp + 2);
 }
 
@@ -1792,6 +1812,9 @@ __global__ __launch_bounds__(1024, 2) void k_lfc_block_s(const uint8_t *__restri
   uint32_t t = chain_temp();
   LFC_STAMP(0);
   LFC_WSTAMP(0);
+  uint32_t wl[16], wh[16];
+  int nt;
+  lfc_row_regs16<13>(r0, tid, wl, wh, nt);  // layer 0's row: its trip to L2 runs behind the binarisation below
   // binarizeAndPack into A: one lane per output word (words 13..15 of an image are never read by layer 0)
   for (int idx = tid; idx < cnt * 16; idx += 1024) {
     const int i = idx >> 4, k = idx & 15;
@@ -1813,34 +1836,44 @@ __global__ __launch_bounds__(1024, 2) void k_lfc_block_s(const uint8_t *__restri
   LFC_WSTAMP(2);
   // The SIMD's arbiter serves the OLDEST wave first.  With two blocks per CU that made the older block run three
   // layers in 40 us while the younger one was still in its first, which then ran the rest alone at half the issue
-  // rate: 244 of 500 blocks finished at 40 us, the other 244 at 61 (per-wave clock stamps, profiles/r03_lfc_block_stamps.txt).
+  // rate: 244 of 500 blocks finished at 40 us, the other 244 at 61 (per-wave clock stamps, profiles/r03_lfc_block_stamps*.txt).
   // So a wave's priority falls with the layer it is in: whichever block is behind goes first, the two stay within a
-  // layer of each other and the SIMDs have eight waves to choose from until the end.
+  // layer of each other and the SIMDs have eight waves to choose from until the end (10 000 images 62.0 -> 57.0 us).
   LFC_PRIO(3);
-  lfc_block_layer_s<13>(r0, tid, A, B, cnt, wave, lane, t, 3);
+#ifdef BNN_LFC_PRIO_QUARTER
+  lfc_block_layer_s<13, 16, 2>(r1, tid, wl, wh, nt, A, B, cnt, wave, lane, t, 3, (3 * cnt) >> 2);
+  LFC_STAMP(2);
+  lfc_block_handoff();
+  LFC_STAMP(3);
+  LFC_WSTAMP(6);
+  lfc_block_layer_s<16, 16, 1>(r2, tid, wl, wh, nt, B, A, cnt, wave, lane, t, 7, cnt >> 1);
+  lfc_block_handoff();
+  LFC_STAMP(4);
+  LFC_WSTAMP(10);
+  lfc_block_layer_s<16, 16, 0>(r3, lane, wl, wh, nt, A, B, cnt, wave, lane, t, 11, cnt >> 2);
+#else
+  lfc_block_layer_s<13, 16>(r1, tid, wl, wh, nt, A, B, cnt, wave, lane, t, 3);
   LFC_STAMP(2);
   lfc_block_handoff();
   LFC_STAMP(3);
   LFC_WSTAMP(6);
   LFC_PRIO(2);
-  lfc_block_layer_s<16>(r1, tid, B, A, cnt, wave, lane, t, 7);
+  lfc_block_layer_s<16, 16>(r2, tid, wl, wh, nt, B, A, cnt, wave, lane, t, 7);
   lfc_block_handoff();
   LFC_STAMP(4);
   LFC_WSTAMP(10);
   LFC_PRIO(1);
-  lfc_block_layer_s<16>(r2, tid, A, B, cnt, wave, lane, t, 11);
+  lfc_block_layer_s<16, 16>(r3, lane, wl, wh, nt, A, B, cnt, wave, lane, t, 11);  // (layer 3: 64 neurons, neuron = lane in every wave)
+#endif
   lfc_block_handoff();
   LFC_STAMP(5);
   LFC_WSTAMP(14);
   LFC_PRIO(0);
-  {  // layer 3 (64 neurons: neuron = lane in every wave) + decode: the waves share out the images
-    uint32_t wl[16], wh[16];
-    int nt;
-    lfc_row_regs<16>(r3, lane, wl, wh, nt);
+  {  // layer 3 + decode: the waves share out the images
     v16u lo, hi;
     for (int i = wave; i < cnt; i += 16) {
       sload_image(B + (size_t)i * 16, lo, hi);
-      const uint64_t word = __ballot(lfc_neuron_s<16>(wl, wh, nt, lo, hi, t) < 0);
+      const uint64_t word = __ballot(lfc_neuron_s<16, 16>(wl, wh, nt, lo, hi, t) < 0);
       if (lane == 0) {
         words[img0 + i] = word;
         if (classes) {

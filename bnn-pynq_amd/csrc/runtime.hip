@@ -59,20 +59,22 @@ constexpr unsigned kTimeEventFlags = hipEventReleaseToDevice;
 constexpr int kHostChunk = 32768;  // host-buffer / file path: H2D of chunk i+1 overlaps the stages of chunk i (largest chunk)
 constexpr int kHeadChunk = 2048;   // ... the first chunk: what the stages wait for before anything runs
 constexpr int kTailChunk = 4096;   // ... the last chunk: whose stages run after the last byte has arrived
+constexpr int kChunkGrowthPct = 200;  // ... and each chunk this much of the one before (towards kHostChunk)
 
 // Chunk boundaries of a host-buffer / file call: base[c] .. base[c+1] are the images of chunk c.
 // The pipeline is copy | stages, double buffered.  With equal chunks the first copy (32 768 CIFAR records =
 // 100 MB: ~3 ms of pread + H2D) runs with the GPU idle and the last chunk's stages (~2.7 ms) run with the link idle.
 // So the chunks ramp: 2048, 4096, ... doubling up to kHostChunk from the front, and 4096, 8192, ... from the back
 // (what is left goes in the middle), and at most ~0.5 ms is exposed at either end.
-// BNN_MI355X_CHUNKS=head:tail:max overrides the three sizes (0 = no ramp at that end; tuning / A-B runs).
+// BNN_MI355X_CHUNKS=head:tail:max[:growth%] overrides the sizes (0 = no ramp at that end; tuning / A-B runs).
 std::vector<int> plan_chunks(int n, bool single) {
   // (sizes are tuned in bytes on CIFAR records: an MNIST image is a quarter of one)
   const int scale = net_spec(BNN_NETWORK).is_cnv ? 1 : 4;
-  int head = kHeadChunk * scale, tail = kTailChunk * scale, big = kHostChunk;
+  int head = kHeadChunk * scale, tail = kTailChunk * scale, big = kHostChunk, growth = kChunkGrowthPct;
   if (const char *e = std::getenv("BNN_MI355X_CHUNKS")) {
-    int h = 0, t = 0, b = 0;
-    if (std::sscanf(e, "%d:%d:%d", &h, &t, &b) == 3 && b >= 256 && b <= kHostChunk && h >= 0 && t >= 0) { head = h; tail = t; big = b; }
+    int h = 0, t = 0, b = 0, g = kChunkGrowthPct;
+    const int got = std::sscanf(e, "%d:%d:%d:%d", &h, &t, &b, &g);
+    if (got >= 3 && b >= 256 && b <= kHostChunk && h >= 0 && t >= 0 && g > 100 && g <= 400) { head = h; tail = t; big = b; growth = g; }
   }
   std::vector<int> front, back;
   int rem = n;
@@ -80,18 +82,22 @@ std::vector<int> plan_chunks(int n, bool single) {
     front.push_back(n);
     rem = 0;
   }
+  auto grow = [&](int s) {
+    const long long g = ((long long)s * growth / 100 + 255) & ~255LL;  // whole 256-image blocks
+    return (int)(g < big ? g : big);
+  };
   int sf = head > 0 ? head : big, sb = tail > 0 ? tail : big;
   if (sf > big) sf = big;
   while (rem > 0) {
     int t = sf < rem ? sf : rem;
     front.push_back(t);
     rem -= t;
-    sf = 2 * sf < big ? 2 * sf : big;
+    sf = grow(sf);
     if (rem > 0 && sb < big) {
       t = sb < rem ? sb : rem;
       back.push_back(t);
       rem -= t;
-      sb = 2 * sb < big ? 2 * sb : big;
+      sb = grow(sb);
     }
   }
   std::vector<int> base;
@@ -426,8 +432,8 @@ int usable_cpus() {
 }
 
 struct Feeder {
-  static constexpr int kSlots = 16;
-  static constexpr size_t kSlotBytes = 4u << 20;
+  static constexpr int kSlots = 12;
+  size_t kSlotBytes = 8u << 20;  // BNN_MI355X_FEEDER_PIECE_MB overrides (tuning): h2d_probe: 4 MB pieces 49 GB/s, 8 MB 52, 16 MB 54
   struct Piece { int chunk; size_t off_in_chunk, src_off, bytes; bool last_of_chunk; };
   uint8_t *ring = nullptr;  // kSlots x kSlotBytes, pinned
   hipEvent_t sent[kSlots] = {};
@@ -480,6 +486,10 @@ struct Feeder {
   // pinned ring, events and worker threads: once per process (the threads sleep between jobs)
   int init() {
     if (ring) return 0;
+    if (const char *e = std::getenv("BNN_MI355X_FEEDER_PIECE_MB")) {
+      const int mb = std::atoi(e);
+      if (mb >= 1 && mb <= 32) kSlotBytes = (size_t)mb << 20;
+    }
     if (hipHostMalloc(reinterpret_cast<void **>(&ring), kSlots * kSlotBytes, hipHostMallocDefault) != hipSuccess) { ring = nullptr; return -1; }
     for (auto &e : sent)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -1;
@@ -551,8 +561,8 @@ int feed_chunks(const uint8_t *mem, int fd, size_t first, size_t rec, size_t ski
   std::vector<Feeder::Piece> pieces;
   for (int c = 0; c < nchunks; c++) {
     const size_t bytes = (size_t)(plan[c + 1] - plan[c]) * rec, src0 = first + (size_t)plan[c] * rec;
-    for (size_t o = 0; o < bytes; o += Feeder::kSlotBytes) {
-      const size_t b = bytes - o < Feeder::kSlotBytes ? bytes - o : Feeder::kSlotBytes;
+    for (size_t o = 0; o < bytes; o += F.kSlotBytes) {
+      const size_t b = bytes - o < F.kSlotBytes ? bytes - o : F.kSlotBytes;
       pieces.push_back({c, o, src0 + o, b, o + b == bytes});
     }
   }
@@ -581,7 +591,7 @@ int feed_chunks(const uint8_t *mem, int fd, size_t first, size_t rec, size_t ski
     uint8_t *chunk_dst = skip ? r.d_rec[slot] : r.d_images[slot];
     // the chunk buffer of two chunks ago: its stages (no label bytes) / its strip kernel (same stream: in order) are done
     if (!skip && pc.off_in_chunk == 0 && c >= 2) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));
-    HIP_OK(hipMemcpyAsync(chunk_dst + pc.off_in_chunk, F.ring + (p % Feeder::kSlots) * Feeder::kSlotBytes, pc.bytes, hipMemcpyHostToDevice,
+    HIP_OK(hipMemcpyAsync(chunk_dst + pc.off_in_chunk, F.ring + (p % Feeder::kSlots) * F.kSlotBytes, pc.bytes, hipMemcpyHostToDevice,
                           r.copy_stream));
     HIP_OK(hipEventRecord(F.sent[p % Feeder::kSlots], r.copy_stream));
     issued = p + 1;
@@ -630,7 +640,11 @@ int infer_host(const uint8_t *imgs, int n, int ncls, int32_t *classes, int16_t *
     return enqueue(r.d_images[slot], m, ncls, classes ? r.d_classes + base : nullptr, want_scores ? r.d_scores + (size_t)base * 64 : nullptr,
                    r.d_words + base, r.stream, r.time_events[2 * c], r.time_events[2 * c + 1]);
   };
-  const bool fed = nchunks > 1 && use_feeder((size_t)n * isz);  // large call: pinned ring, filled by worker threads (above)
+  // The pinned ring is for FILES.  A buffer in host memory goes faster without it: the runtime's own pageable path moves
+  // a 100 MB chunk at 54 GB/s (profiles/r03_h2d_probe.txt), the ring's 4-8 MB pieces reach 49-52 and add a copy
+  // (measured, same box: 13.8 ms through the ring, 12.7 ms without, 131 072 CIFAR images).  BNN_MI355X_FEED_HOST=1 forces it.
+  static const bool feed_host = std::getenv("BNN_MI355X_FEED_HOST") != nullptr;
+  const bool fed = feed_host && nchunks > 1 && use_feeder((size_t)n * isz);
   if (fed && feed_chunks(imgs, -1, 0, isz, 0, plan, stages)) return -1;
   for (int c = 0; c < (fed ? 0 : nchunks); c++) {
     const int base = plan[c], m = plan[c + 1] - plan[c], slot = c & 1;

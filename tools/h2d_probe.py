@@ -53,3 +53,46 @@ for T in (1, 2, 4, 8, 12, 16):
         run()
         t.append(time.perf_counter() - t0)
     print("memcpy pageable -> pinned, %2d threads: %.2f ms = %.1f GB/s" % (T, min(t) * 1e3, N / min(t) / 1e9), flush=True)
+# a file in the page cache, mapped: does the runtime's pageable path take it at link speed?
+import mmap, os, tempfile
+with tempfile.NamedTemporaryFile(dir="/tmp", suffix=".bin") as f:
+    f.write(a.tobytes())
+    f.flush()
+    for populate in (False, True):
+        t = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            fd = os.open(f.name, os.O_RDONLY)
+            mm = mmap.mmap(fd, N, flags=mmap.MAP_SHARED | (mmap.MAP_POPULATE if populate else 0), prot=mmap.PROT_READ)
+            src = torch.frombuffer(mm, dtype=torch.uint8)
+            t1 = time.perf_counter()
+            dst.copy_(src, non_blocking=True)
+            torch.cuda.synchronize()
+            t.append((time.perf_counter() - t0, time.perf_counter() - t1))
+            del src
+            mm.close()
+            os.close(fd)
+        b = min(t)
+        print("mmap'ed file (populate=%s) -> HBM: %.2f ms incl. mmap (copy alone %.2f ms) = %.1f GB/s" % (populate, b[0] * 1e3, b[1] * 1e3, N / b[0] / 1e9), flush=True)
+    # pread into pinned memory, T threads
+    fd = os.open(f.name, os.O_RDONLY)
+    pv = memoryview(b if False else pinned.numpy())
+    for T in (1, 2, 4, 8, 12, 16):
+        part = (N + T - 1) // T
+
+        def rd(lo):
+            hi = min(lo + part, N)
+            o = lo
+            while o < hi:
+                o += os.preadv(fd, [pv[o:hi]], o)
+        tt = []
+        for _ in range(4):
+            th = [threading.Thread(target=rd, args=(lo,)) for lo in range(0, N, part)]
+            t0 = time.perf_counter()
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            tt.append(time.perf_counter() - t0)
+        print("pread page cache -> pinned, %2d threads: %.2f ms = %.1f GB/s" % (T, min(tt) * 1e3, N / min(tt) / 1e9), flush=True)
+    os.close(fd)
