@@ -344,12 +344,12 @@ def main():
     for _ in range(a.warmup):
         step()
     barrier()
-    # HIP events around every stage, on the stream the kernels run on, inside the timed region -- at the batch sizes where the
-    # dispatch policy IS the staged form (the default 131 072 images and everything above 32 768).  Below that the library may
+    # HIP events around every stage, on the stream the kernels run on, inside the timed region -- where the dispatch policy IS
+    # the staged form (the CNV nets above 32 768 images: the default 131 072).  Elsewhere the library may
     # run a network as ONE launch (k_lfc_block_s, k_lfc_fused, k_cnv_tail), which per-stage events would switch off: `value`
     # is then timed on the shipped policy without events, and the per-stage breakdown comes from a second pass of the same K
     # steps with events (roofline.stage_times_source says which).
-    events_in_region = a.batch > 32768
+    events_in_region = is_cnv and a.batch > 32768   # (lfcW1A1 is one k_lfc_block_s launch up to 131 072 images, lfcW1A2 up to 2 048)
     L.bnn_mi355x_profile(1 if events_in_region else 0)
     t0 = time.perf_counter()
     for _ in range(a.steps):

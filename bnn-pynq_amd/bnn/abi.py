@@ -64,7 +64,7 @@ def declare_extensions(L):
     L.bnn_mi355x_inference_device.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_void_p]
     L.bnn_mi355x_reserve.argtypes = [C.c_int]
-    L.bnn_mi355x_chunk_plan.argtypes = [C.c_int, ip, C.c_int]
+    L.bnn_mi355x_chunk_plan.argtypes = [C.c_int, C.c_int, ip, C.c_int]
     L.bnn_mi355x_set_fault_seed.argtypes = [C.c_ulonglong]
     L.bnn_mi355x_last_faults.argtypes = [ip, C.c_int]
     L.bnn_mi355x_plan_faults.argtypes = [C.c_ulonglong, C.c_int, C.c_uint, C.c_int, C.c_int, ip, C.c_uint, ip, C.c_int]

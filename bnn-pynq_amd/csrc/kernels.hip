@@ -1907,14 +1907,15 @@ __global__ __launch_bounds__(kBlock) void k_lfc_decode(const uint64_t *__restric
   classes[i] = w ? 63 - __builtin_clzll(w) : 0;
 }
 
-// images: up to here lfcW1A1 runs as one k_lfc_block_s launch; measured against the staged path
-// (profiles/r02_lfc_block_sweep.txt, us per batch): 4 097 images 35 vs 58, 6 000 42 vs 58, 10 000 61 vs 74,
-// 16 384 88 vs 96, 24 576 122 vs 129, 32 768 161 vs 163, 65 536 310 vs 304: beyond ~40 000 the staged kernels win
-// (64 pairs per scalar-load wait instead of 32).  BNN_MI355X_LFC_BLOCK_MAX overrides (tools/batch_sweep.py).
+// images: up to here lfcW1A1 runs as one k_lfc_block_s launch.  Round 2 (oldest-wave-first arbitration left to itself)
+// it lost to the staged kernels beyond ~40 000 images; with the per-layer wave priorities it wins over the whole range
+// of one pass (profiles/r03_lfc_block_priorities.txt, us per batch, block vs staged): 32 768 images 161 vs 175,
+// 49 152 219 vs 239, 65 536 286 vs 304, 98 304 425 vs 438, 131 072 565 vs 572.  BNN_MI355X_LFC_BLOCK_MAX overrides
+// (tools/batch_sweep.py); the staged kernels remain what per-stage profiling and the stage-output test hook run.
 inline long long lfc_block_max() {
   static const long long v = [] {
     const char *e = std::getenv("BNN_MI355X_LFC_BLOCK_MAX");
-    return e ? std::atoll(e) : 32768LL;
+    return e ? std::atoll(e) : 131072LL;
   }();
   return v;
 }

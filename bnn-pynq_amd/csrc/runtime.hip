@@ -58,21 +58,23 @@ constexpr int kMaxChunk = 131072;  // images per pass through the stages
 constexpr unsigned kTimeEventFlags = hipEventReleaseToDevice;
 constexpr int kHostChunk = 32768;  // host-buffer / file path: H2D of chunk i+1 overlaps the stages of chunk i (largest chunk)
 constexpr int kHeadChunk = 2048;   // ... the first chunk: what the stages wait for before anything runs
-constexpr int kTailChunk = 4096;   // ... the last chunk: whose stages run after the last byte has arrived
-constexpr int kChunkGrowthPct = 200;  // ... and each chunk this much of the one before (towards kHostChunk)
 
 // Chunk boundaries of a host-buffer / file call: base[c] .. base[c+1] are the images of chunk c.
 // The pipeline is copy | stages, double buffered.  With equal chunks the first copy (32 768 CIFAR records =
-// 100 MB: ~3 ms of pread + H2D) runs with the GPU idle and the last chunk's stages (~2.7 ms) run with the link idle.
-// So the chunks ramp: 2048, 4096, ... doubling up to kHostChunk from the front, and 4096, 8192, ... from the back
-// (what is left goes in the middle), and at most ~0.5 ms is exposed at either end.
+// 100 MB: ~3 ms of pread + H2D) runs with the GPU idle, so the chunks ramp up from 2 048 images -- by a factor that
+// keeps the NEXT chunk's transfer shorter than THIS chunk's stages, or the stages starve at every step of the ramp
+// (measured with a device timeline, profiles/r03_host_path_timelines.txt: doubling left 0.3-0.8 ms holes):
+//   * a buffer in host memory arrives at 54 GB/s = 17.6 M CIFAR images/s against 12.5 M/s of stages: x1.5 per
+//     step; the call is compute-bound, its end is the last chunk's stages whatever their size: no ramp down;
+//   * a file arrives at ~35 GB/s (pread from the page cache + DMA), a little slower than the stages: x1.25, and the
+//     chunks ramp down again towards the end (what follows the last byte is the last chunk's stages).
 // BNN_MI355X_CHUNKS=head:tail:max[:growth%] overrides the sizes (0 = no ramp at that end; tuning / A-B runs).
-std::vector<int> plan_chunks(int n, bool single) {
+std::vector<int> plan_chunks(int n, bool single, bool from_file) {
   // (sizes are tuned in bytes on CIFAR records: an MNIST image is a quarter of one)
   const int scale = net_spec(BNN_NETWORK).is_cnv ? 1 : 4;
-  int head = kHeadChunk * scale, tail = kTailChunk * scale, big = kHostChunk, growth = kChunkGrowthPct;
+  int head = kHeadChunk * scale, tail = from_file ? kHeadChunk * scale : 0, big = kHostChunk, growth = from_file ? 125 : 150;
   if (const char *e = std::getenv("BNN_MI355X_CHUNKS")) {
-    int h = 0, t = 0, b = 0, g = kChunkGrowthPct;
+    int h = 0, t = 0, b = 0, g = growth;
     const int got = std::sscanf(e, "%d:%d:%d:%d", &h, &t, &b, &g);
     if (got >= 3 && b >= 256 && b <= kHostChunk && h >= 0 && t >= 0 && g > 100 && g <= 400) { head = h; tail = t; big = b; growth = g; }
   }
@@ -437,6 +439,9 @@ struct Feeder {
   struct Piece { int chunk; size_t off_in_chunk, src_off, bytes; bool last_of_chunk; };
   uint8_t *ring = nullptr;  // kSlots x kSlotBytes, pinned
   hipEvent_t sent[kSlots] = {};
+  // A/B (BNN_MI355X_FEEDER_STREAMS=2): odd pieces go through a second stream, i.e. a second DMA queue
+  hipStream_t aux = nullptr;
+  hipEvent_t aux_done = nullptr;
   std::vector<std::thread> workers;
   std::mutex mu;
   std::condition_variable cv_job, cv_done;
@@ -493,6 +498,11 @@ struct Feeder {
     if (hipHostMalloc(reinterpret_cast<void **>(&ring), kSlots * kSlotBytes, hipHostMallocDefault) != hipSuccess) { ring = nullptr; return -1; }
     for (auto &e : sent)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -1;
+    if (const char *e = std::getenv("BNN_MI355X_FEEDER_STREAMS"))
+      if (std::atoi(e) == 2) {
+        if (hipStreamCreateWithFlags(&aux, hipStreamNonBlocking) != hipSuccess) return -1;
+        if (hipEventCreateWithFlags(&aux_done, hipEventDisableTiming) != hipSuccess) return -1;
+      }
     int nt = usable_cpus() - 2;  // leave a core to the calling thread and one to the driver's
     if (const char *e = std::getenv("BNN_MI355X_FEEDER_THREADS")) nt = std::atoi(e);
     nt = nt < 1 ? 1 : (nt > 14 ? 14 : nt);
@@ -590,13 +600,20 @@ int feed_chunks(const uint8_t *mem, int fd, size_t first, size_t rec, size_t ski
     }
     uint8_t *chunk_dst = skip ? r.d_rec[slot] : r.d_images[slot];
     // the chunk buffer of two chunks ago: its stages (no label bytes) / its strip kernel (same stream: in order) are done
-    if (!skip && pc.off_in_chunk == 0 && c >= 2) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));
-    HIP_OK(hipMemcpyAsync(chunk_dst + pc.off_in_chunk, F.ring + (p % Feeder::kSlots) * F.kSlotBytes, pc.bytes, hipMemcpyHostToDevice,
-                          r.copy_stream));
-    HIP_OK(hipEventRecord(F.sent[p % Feeder::kSlots], r.copy_stream));
+    if (pc.off_in_chunk == 0 && c >= 2) {
+      if (!skip) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));
+      if (F.aux) HIP_OK(hipStreamWaitEvent(F.aux, skip ? r.copied[slot] : r.consumed[slot], 0));  // (copied: recorded behind the strip)
+    }
+    hipStream_t ds = (F.aux && (p & 1)) ? F.aux : r.copy_stream;
+    HIP_OK(hipMemcpyAsync(chunk_dst + pc.off_in_chunk, F.ring + (p % Feeder::kSlots) * F.kSlotBytes, pc.bytes, hipMemcpyHostToDevice, ds));
+    HIP_OK(hipEventRecord(F.sent[p % Feeder::kSlots], ds));
     issued = p + 1;
     release_done();
     if (!pc.last_of_chunk) continue;
+    if (F.aux) {  // the chunk is complete when both queues have delivered their pieces
+      HIP_OK(hipEventRecord(F.aux_done, F.aux));
+      HIP_OK(hipStreamWaitEvent(r.copy_stream, F.aux_done, 0));
+    }
     const int base = plan[c], m = plan[c + 1] - plan[c];
     if (skip) {
       if (c >= 2) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));  // d_images[slot] free again
@@ -622,7 +639,7 @@ int infer_host(const uint8_t *imgs, int n, int ncls, int32_t *classes, int16_t *
   if (n <= 0) return 0;
   const size_t isz = (size_t)r.spec.image_bytes();
   // (the stage-output test hook reads the workspace after the call: all images must be in it, one chunk)
-  const std::vector<int> plan = plan_chunks(n, r.debug_last_stage >= 0);
+  const std::vector<int> plan = plan_chunks(n, r.debug_last_stage >= 0, false);
   const int chunk = largest_chunk(plan);
   const int nchunks = (int)plan.size() - 1;
   if (reserve(chunk) || reserve_host(chunk, (size_t)n)) return -1;
@@ -793,7 +810,7 @@ struct ChunkReader {
 template <typename Dst, typename Consume>
 int stream_file(const ImageFile &f, int n, bool reuse_slots, Dst dst, Consume consume) {
   Runtime &r = rt();
-  const std::vector<int> plan = plan_chunks(n, false);
+  const std::vector<int> plan = plan_chunks(n, false, true);
   const int chunk = largest_chunk(plan);
   const int nchunks = (int)plan.size() - 1;
   const size_t chunk_bytes = (size_t)chunk * f.rec;
@@ -863,7 +880,7 @@ int infer_file(const ImageFile &f, int n, int ncls, int32_t *classes, int16_t *s
   if (ncls < 1 || ncls > 64) return fail("number_class must be in 1..64");
   if (usec) *usec = 0.f;
   if (n <= 0) return 0;
-  const std::vector<int> plan = plan_chunks(n, false);  // (stream_file walks the same plan)
+  const std::vector<int> plan = plan_chunks(n, false, true);  // (stream_file walks the same plan)
   const int chunk = largest_chunk(plan);
   const int nchunks = (int)plan.size() - 1;
   if (reserve(chunk) || reserve_host(chunk, (size_t)n)) return -1;
@@ -1258,9 +1275,9 @@ int bnn_mi355x_debug_lfc_wstamps(unsigned long long *dst) {
 }
 #endif
 
-int bnn_mi355x_chunk_plan(int n_images, int *bases, int cap) {
+int bnn_mi355x_chunk_plan(int n_images, int from_file, int *bases, int cap) {
   if (n_images < 0) return fail("chunk_plan: bad arguments");
-  const std::vector<int> plan = plan_chunks(n_images, false);
+  const std::vector<int> plan = plan_chunks(n_images, false, from_file != 0);
   for (size_t i = 0; i < plan.size() && (int)i < cap && bases; i++) bases[i] = plan[i];
   return (int)plan.size();
 }

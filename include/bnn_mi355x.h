@@ -143,12 +143,14 @@ int bnn_mi355x_inference_device(const void *d_images, int n_images, int number_c
                                 int16_t *d_scores, uint64_t *d_words, void *hip_stream);
 int bnn_mi355x_reserve(int max_images);
 
-/* How the entry points that take HOST data (inference_multiple(path), inference_buffer, inference_raw) cut a
- * call of n images into chunks whose transfer overlaps the previous chunk's stages: writes the chunk
- * boundaries base[0] = 0 < base[1] < ... < base[k] = n (at most cap of them) and returns k + 1.  Small chunks
- * at both ends (the first transfer and the last chunk's stages are the only parts nothing overlaps), 32 768
- * images in between.  Host only; results never depend on the plan (tests/test_gpu_parity.py walks its edges). */
-int bnn_mi355x_chunk_plan(int n_images, int *bases, int cap);
+/* How the entry points that take HOST data cut a call of n images into chunks whose transfer overlaps the
+ * previous chunk's stages -- from_file != 0: inference_multiple(path) (the chunks ramp up x1.25 from 2 048 images
+ * and down again at the end: the file arrives a little slower than the stages run); from_file == 0:
+ * inference_buffer / inference_raw (x1.5 up, no ramp down: host memory arrives faster than the stages).  Writes
+ * the chunk boundaries base[0] = 0 < base[1] < ... < base[k] = n (at most cap of them) and returns k + 1; no chunk
+ * holds more than 32 768 images.  Host only; results never depend on the plan (tests/test_gpu_parity.py walks
+ * its edges). */
+int bnn_mi355x_chunk_plan(int n_images, int from_file, int *bases, int cap);
 
 /* Fault campaigns: fix the seed of the fault planner (0 = std::random_device like the
  * reference, the default) and read back the faults of the last

@@ -389,9 +389,12 @@ def test_file_abi_streams_multi_chunk_files(network, dataset, n, tmp_path):
     # both entry points cut the call by the same plan (ramped chunks): the images either side of every chunk edge,
     # against the oracle, which knows nothing of chunks
     bases = (C.c_int * 64)()
-    k = L.bnn_mi355x_chunk_plan(n, bases, 64)
-    edges = [bases[i] for i in range(k)]
-    assert k >= 4 and edges[0] == 0 and edges[-1] == n and all(0 < b - a <= 32768 for a, b in zip(edges, edges[1:]))
+    edges = set()
+    for from_file in (0, 1):      # `want` came through the host-buffer plan, `got` through the file plan
+        k = L.bnn_mi355x_chunk_plan(n, from_file, bases, 64)
+        e = [bases[i] for i in range(k)]
+        assert 4 <= k <= 64 and e[0] == 0 and e[-1] == n and all(0 < b - a <= 32768 for a, b in zip(e, e[1:]))
+        edges |= set(e)
     near = sorted({min(max(e + d, 0), n - 1) for e in edges for d in (-2, -1, 0, 1)})
     assert (got[near] == oracle(network, dataset).classes_batched(imgs[near], 10)).all()
     if cnv:
@@ -601,7 +604,7 @@ def test_device_calls_on_two_streams_share_the_workspace_safely():
 
 @pytest.mark.parametrize("n", [4097, 4351, 4352, 5000, 10000, 16383, 32768, 32769, 70000])
 def test_lfc_mid_batches_take_the_block_kernel(n):
-    """lfcW1A1 between the one-launch small-batch kernel (<= 4096 images) and the staged throughput path (> 32 768):
+    """lfcW1A1 beyond the one-launch small-batch kernel (<= 4096 images), up to one pass of 131 072 images:
     one k_lfc_block_s launch, a 1024-thread block per ceil(n / 512) images walking all four layers with the
     activations fed through SGPRs (BASELINE config 2 is 10 000 images).  Sizes either side of the policy edges,
     ragged last blocks, raw words through the host path and classes through the device path."""
@@ -640,6 +643,10 @@ def test_lfc_block_kernel_beyond_its_policy_range():
         "    assert (c.cpu().numpy() == o.classes_batched(imgs, 10)).all(), n\n"
         "print('block-ok')\n" % (os.path.join(gl.ROOT, "tests"), os.path.join(gl.ROOT, "bnn-pynq_amd")))
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BNN_MI355X_LFC_BLOCK_MAX="1000000"), capture_output=True, text=True, timeout=600)
+    assert "block-ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
+    # ... and the staged kernels (one launch per layer, a lane per image), which the policy now only runs for per-stage
+    # profiling: the same batches with the block kernel switched off
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BNN_MI355X_LFC_BLOCK_MAX="0"), capture_output=True, text=True, timeout=600)
     assert "block-ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
 
 

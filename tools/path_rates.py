@@ -66,7 +66,7 @@ with tempfile.NamedTemporaryFile(dir="/tmp", suffix=".bin") as f:
     os.dup2(saved, 1)
     assert (res == want).all()
 bases = (C.c_int * 128)()
-k = L.bnn_mi355x_chunk_plan(n, bases, 128)
+k = L.bnn_mi355x_chunk_plan(n, 1, bases, 128)
 print("%s n=%d plan=%s chunks=%d | resident %.2f ms (%.2f M/s) | host buffer best %.2f ms (%.2f M/s) median %.2f | file best %.2f ms (%.2f M/s) median %.2f"
       % (net, n, os.environ.get("BNN_MI355X_CHUNKS", "default"), k - 1, resident * 1e3, n / resident / 1e6, min(host) * 1e3, n / min(host) / 1e6,
          sorted(host)[len(host) // 2] * 1e3, min(filet[1:]) * 1e3, n / min(filet[1:]) / 1e6, sorted(filet[1:])[len(filet[1:]) // 2] * 1e3), flush=True)

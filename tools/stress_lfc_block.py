@@ -22,7 +22,7 @@ L.load_parameters(gl.param_dir("mnist", "lfcW1A1").encode())
 o = ol.Oracle("lfcW1A1", ol.param_dir("mnist", "lfcW1A1"))
 C = gl.load("cnvW1A1")
 C.load_parameters(gl.param_dir("cifar10", "cnvW1A1").encode())
-hi = int(os.environ.get("BNN_MI355X_LFC_BLOCK_MAX", "32768"))
+hi = int(os.environ.get("BNN_MI355X_LFC_BLOCK_MAX", "131072"))
 cimgs = torch.randint(0, 256, (3000, 3072), dtype=torch.uint8, device="cuda")
 ccls = torch.zeros(3000, dtype=torch.int32, device="cuda")
 s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
