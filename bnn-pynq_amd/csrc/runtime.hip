@@ -435,13 +435,11 @@ int usable_cpus() {
 
 struct Feeder {
   static constexpr int kSlots = 12;
-  size_t kSlotBytes = 8u << 20;  // BNN_MI355X_FEEDER_PIECE_MB overrides (tuning): h2d_probe: 4 MB pieces 49 GB/s, 8 MB 52, 16 MB 54
+  size_t kSlotBytes = 4u << 20;  // BNN_MI355X_FEEDER_PIECE_MB overrides (tuning): alone, 4 MB pieces move at 49 GB/s, 8 MB at 52, 16 MB at 54
+                                 // (profiles/r03_h2d_probe.txt); behind the readers 2-4 MB pieces gave the shortest calls
   struct Piece { int chunk; size_t off_in_chunk, src_off, bytes; bool last_of_chunk; };
   uint8_t *ring = nullptr;  // kSlots x kSlotBytes, pinned
   hipEvent_t sent[kSlots] = {};
-  // A/B (BNN_MI355X_FEEDER_STREAMS=2): odd pieces go through a second stream, i.e. a second DMA queue
-  hipStream_t aux = nullptr;
-  hipEvent_t aux_done = nullptr;
   std::vector<std::thread> workers;
   std::mutex mu;
   std::condition_variable cv_job, cv_done;
@@ -498,12 +496,11 @@ struct Feeder {
     if (hipHostMalloc(reinterpret_cast<void **>(&ring), kSlots * kSlotBytes, hipHostMallocDefault) != hipSuccess) { ring = nullptr; return -1; }
     for (auto &e : sent)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -1;
-    if (const char *e = std::getenv("BNN_MI355X_FEEDER_STREAMS"))
-      if (std::atoi(e) == 2) {
-        if (hipStreamCreateWithFlags(&aux, hipStreamNonBlocking) != hipSuccess) return -1;
-        if (hipEventCreateWithFlags(&aux_done, hipEventDisableTiming) != hipSuccess) return -1;
-      }
+    // Readers: 4 pread() threads already move 45 GB/s out of the page cache (8: 74 GB/s), more than the link takes;
+    // beyond ~6 the DMA, which reads the lines they have just written, slows down more than they speed up
+    // (profiles/r03_file_path_sweep.txt: 2 threads 20.4 ms per 131 072-record file, 4: 12.9-14.7, 6: 14.1, 14: 14.2).
     int nt = usable_cpus() - 2;  // leave a core to the calling thread and one to the driver's
+    nt = nt > 6 ? 6 : nt;
     if (const char *e = std::getenv("BNN_MI355X_FEEDER_THREADS")) nt = std::atoi(e);
     nt = nt < 1 ? 1 : (nt > 14 ? 14 : nt);
     for (int i = 0; i < nt; i++) workers.emplace_back([this] { worker(); });
@@ -600,20 +597,14 @@ int feed_chunks(const uint8_t *mem, int fd, size_t first, size_t rec, size_t ski
     }
     uint8_t *chunk_dst = skip ? r.d_rec[slot] : r.d_images[slot];
     // the chunk buffer of two chunks ago: its stages (no label bytes) / its strip kernel (same stream: in order) are done
-    if (pc.off_in_chunk == 0 && c >= 2) {
-      if (!skip) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));
-      if (F.aux) HIP_OK(hipStreamWaitEvent(F.aux, skip ? r.copied[slot] : r.consumed[slot], 0));  // (copied: recorded behind the strip)
-    }
-    hipStream_t ds = (F.aux && (p & 1)) ? F.aux : r.copy_stream;
-    HIP_OK(hipMemcpyAsync(chunk_dst + pc.off_in_chunk, F.ring + (p % Feeder::kSlots) * F.kSlotBytes, pc.bytes, hipMemcpyHostToDevice, ds));
-    HIP_OK(hipEventRecord(F.sent[p % Feeder::kSlots], ds));
+    if (!skip && pc.off_in_chunk == 0 && c >= 2) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));
+    // (Odd pieces through a second stream -- a second DMA queue -- was measured: no gain, 13.7 vs 12.9 ms per file.)
+    HIP_OK(hipMemcpyAsync(chunk_dst + pc.off_in_chunk, F.ring + (p % Feeder::kSlots) * F.kSlotBytes, pc.bytes, hipMemcpyHostToDevice,
+                          r.copy_stream));
+    HIP_OK(hipEventRecord(F.sent[p % Feeder::kSlots], r.copy_stream));
     issued = p + 1;
     release_done();
     if (!pc.last_of_chunk) continue;
-    if (F.aux) {  // the chunk is complete when both queues have delivered their pieces
-      HIP_OK(hipEventRecord(F.aux_done, F.aux));
-      HIP_OK(hipStreamWaitEvent(r.copy_stream, F.aux_done, 0));
-    }
     const int base = plan[c], m = plan[c + 1] - plan[c];
     if (skip) {
       if (c >= 2) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));  // d_images[slot] free again
