@@ -76,7 +76,7 @@ std::vector<int> plan_chunks(int n, bool single, bool from_file) {
   if (const char *e = std::getenv("BNN_MI355X_CHUNKS")) {
     int h = 0, t = 0, b = 0, g = growth;
     const int got = std::sscanf(e, "%d:%d:%d:%d", &h, &t, &b, &g);
-    if (got >= 3 && b >= 256 && b <= kHostChunk && h >= 0 && t >= 0 && g > 100 && g <= 400) { head = h; tail = t; big = b; growth = g; }
+    if (got >= 3 && b >= 256 && b <= kMaxChunk && h >= 0 && t >= 0 && g > 100 && g <= 400) { head = h; tail = t; big = b; growth = g; }
   }
   std::vector<int> front, back;
   int rem = n;
@@ -525,18 +525,12 @@ struct Feeder {
     std::unique_lock<std::mutex> lk(mu);
     cv_done.wait(lk, [&] { return active == 0; });
   }
-  ~Feeder() {
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      quit = true;
-      cv_job.notify_all();
-    }
-    for (auto &t : workers) t.join();
-  }
 };
+// One per process, never destroyed: its threads sleep on a condition variable between jobs and end with the process
+// (a static object's destructor would have to join them at exit, behind the HIP runtime's own teardown).
 Feeder &feeder() {
-  static Feeder f;
-  return f;
+  static Feeder *f = new Feeder;
+  return *f;
 }
 bool use_feeder(size_t bytes) {
   static const bool off = std::getenv("BNN_MI355X_NO_FEEDER") != nullptr;

@@ -53,6 +53,7 @@ python3 bench.py --dist-world1 --steps 5 --warmup 2 --no-cpu-baseline --no-extra
 python3 tools/path_rates.py cnvW1A1 131072 7 2>/dev/null | grep -v Setting > $O/path_rates.txt
 python3 tools/path_rates.py cnvW1A1 1048576 3 2>/dev/null | grep -v Setting >> $O/path_rates.txt
 python3 tools/path_rates.py lfcW1A1 131072 7 2>/dev/null | grep -v Setting >> $O/path_rates.txt
+for plan in 32768:0:131072:200 131072:0:131072:200 16384:0:65536:200; do BNN_MI355X_CHUNKS=$plan python3 tools/path_rates.py lfcW1A1 131072 7 2>/dev/null | grep -v Setting >> $O/path_rates.txt; done
 cat $O/path_rates.txt
 BATCHES=1,256,1024,4096,4097,10000,32768,65536,131072 python3 tools/batch_sweep.py lfcW1A1 2>/dev/null | grep -v Setting > $O/batch_sweep_lfcW1A1.txt
 BATCHES=1,256,1024,4096,8191,8192,10000,32768,131072 python3 tools/batch_sweep.py cnvW1A1 2>/dev/null | grep -v Setting > $O/batch_sweep_cnvW1A1.txt
