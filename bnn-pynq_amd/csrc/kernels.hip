@@ -50,7 +50,10 @@ typedef const uint32_t __attribute__((address_space(4))) *kptr32;
 typedef const uint64_t __attribute__((address_space(4))) *kptr64;
 
 constexpr int kBlock = 256;
-constexpr int kLfcFusedMax = 4096, kLfcFusedMaxA2 = 2048;  // images: up to here the one-launch LFC kernels beat the six staged ones (tools/batch_sweep.py)
+constexpr int kLfcFusedMaxA2 = 2048;  // images: up to here lfcW1A2's one-launch kernel beats the six staged ones (tools/batch_sweep.py)
+#ifndef BNN_LFC_ALL_ROWS  // A/B builds: 0 = two weight rows in flight also for a single image
+#define BNN_LFC_ALL_ROWS 1
+#endif
 
 // Block -> (work-item block, neuron group), XCD-aware.  The `groups` blocks that evaluate
 // different 32-neuron groups for the SAME 256 work items read the same input windows and write
@@ -1483,7 +1486,7 @@ __global__ __launch_bounds__(1024) void k_lfc_fused_a2(const uint8_t *__restrict
   uint64_t w0[13], w1[16], w2[16], w3[16];
   int a0, b0, a1, b1, a2, b2, a3 = 0, b3 = 0;
   // (pixels first, all three big rows at entry for a single image: see k_lfc_fused)
-  constexpr bool ALL_ROWS = IPB == 1;
+  constexpr bool ALL_ROWS = IPB == 1 && BNN_LFC_ALL_ROWS;
   uint8_t px[IPB];
 #pragma unroll
   for (int i = 0; i < IPB; i++) {
@@ -1579,7 +1582,7 @@ __global__ __launch_bounds__(1024) void k_lfc_fused(const uint8_t *__restrict__ 
   // A single image is pure latency: four dependent layers behind one trip to L2 each.  With one image per block the
   // rows of ALL layers are requested at entry (90 dwords per thread: the block has the CU to itself, 128 VGPRs);
   // with more images per block two rows are in flight at a time (more would spill at two blocks per CU).
-  constexpr bool ALL_ROWS = IPB == 1;
+  constexpr bool ALL_ROWS = IPB == 1 && BNN_LFC_ALL_ROWS;
   // the pixels are requested first: vector loads return in order, so waiting for them must not mean waiting for rows
   uint8_t px[IPB];
 #pragma unroll
@@ -1673,6 +1676,7 @@ __device__ __forceinline__ void lfc_row_regs(const uint32_t *__restrict__ rows, 
 #ifndef BNN_LFC_CHAINS
 #define BNN_LFC_CHAINS 1
 #endif
+
 #ifdef BNN_LFC_STAMPS
 // diagnostic build only (tools/build_variant.sh ... -DBNN_LFC_STAMPS): wave 0 of every block of k_lfc_block_s writes the
 // 100 MHz wall clock at entry, behind each of the five hand-offs / layers, and at exit: where a launch's time goes
@@ -1912,6 +1916,15 @@ __global__ __launch_bounds__(kBlock) void k_lfc_decode(const uint64_t *__restric
 // of one pass (profiles/r03_lfc_block_priorities.txt, us per batch, block vs staged): 32 768 images 161 vs 175,
 // 49 152 219 vs 239, 65 536 286 vs 304, 98 304 425 vs 438, 131 072 565 vs 572.  BNN_MI355X_LFC_BLOCK_MAX overrides
 // (tools/batch_sweep.py); the staged kernels remain what per-stage profiling and the stage-output test hook run.
+// images: up to here lfcW1A1 runs as k_lfc_fused<IPB> (a block per 1/2/4/8 images), beyond as k_lfc_block_s;
+// BNN_MI355X_LFC_FUSED_MAX overrides (tools/batch_sweep.py)
+inline long long lfc_fused_max() {
+  static const long long v = [] {
+    const char *e = std::getenv("BNN_MI355X_LFC_FUSED_MAX");
+    return e ? std::atoll(e) : 4096LL;
+  }();
+  return v;
+}
 inline long long lfc_block_max() {
   static const long long v = [] {
     const char *e = std::getenv("BNN_MI355X_LFC_BLOCK_MAX");
@@ -2148,7 +2161,7 @@ hipError_t run_lfc(NetId net, const LfcLaunch &a) {
   uint32_t *A = reinterpret_cast<uint32_t *>(a.buf0), *B = reinterpret_cast<uint32_t *>(a.buf1);
   uint64_t *A64 = reinterpret_cast<uint64_t *>(a.buf0), *B64 = reinterpret_cast<uint64_t *>(a.buf1);
   hipStream_t s = a.stream;
-  if (n <= (net == NET_LFCW1A1 ? kLfcFusedMax : kLfcFusedMaxA2) && !a.events && a.last_stage >= kLfcStages - 1) {
+  if (n <= (net == NET_LFCW1A1 ? lfc_fused_max() : kLfcFusedMaxA2) && !a.events && a.last_stage >= kLfcStages - 1) {
     // small batch: the one-launch form, a block per group of IPB images (no per-stage events: there are no
     // stages).  A block costs ~8 us + ~1.6 us per further image whatever the batch, so the group is the
     // smallest that still fits the batch in one round of 256 blocks (profiles/r01_lfc_forms.txt).

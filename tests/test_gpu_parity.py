@@ -719,3 +719,25 @@ def test_device_call_captured_into_a_graph_after_a_call_on_another_stream():
     assert L.bnn_mi355x_inference_device(d_a.data_ptr(), n, 10, out_a.data_ptr(), None, None, None) == 0
     torch.cuda.synchronize()
     assert (out_a.cpu().numpy() == o.classes_batched(a_host, 10)).all()
+
+
+@pytest.mark.parametrize("n", [7809, 7811, 9999])
+def test_file_abi_either_side_of_the_pinned_ring_threshold(n, tmp_path):
+    """files below 24 MB (7 810 CIFAR records) go through a pageable host chunk, larger ones through the ring of pinned
+    pieces that worker threads fill with pread() (feed_chunks): every class of an odd-sized file on both sides, against
+    the oracle; twice in a row (the ring's slots and the workers are reused)"""
+    net = gpu_net("cnvW1A1", "cifar10")
+    imgs = rand_images("cnvW1A1", n, 4000 + n)
+    rec = np.empty((n, 3073), np.uint8)
+    rec[:, 0] = 3
+    rec[:, 1:] = imgs
+    path = tmp_path / "f.bin"
+    path.write_bytes(rec.tobytes())
+    want = oracle("cnvW1A1", "cifar10").classes_batched(imgs, 10)
+    for _ in range(2):
+        cnt = C.c_int(0)
+        p = net.L.inference_multiple(str(path).encode(), 10, C.byref(cnt), None, 0)
+        assert p and cnt.value == n
+        got = np.ctypeslib.as_array(p, (n,)).copy()
+        net.L.free_results(p)
+        assert (got == want).all()

@@ -10,7 +10,8 @@ import gpu_lib as gl
 import oracle_lib as ol
 
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
-edges = {"cnv": [1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 1500, 2049],
+edges = {"cnv": [1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 1500, 2049,
+                 8185, 8191, 8192, 8193, 8199, 9001],      # layer 0: lane per pixel below 8 192 images, blocks of 8 from there
          "lfc": [1, 2, 63, 65, 255, 257, 511, 513, 1023, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 6000, 8191, 12289, 20001,
                  32767, 32768, 32769, 33000]}
 for net, ds in (("cnvW1A1", "cifar10"), ("cnvW1A2", "cifar10"), ("cnvW2A2", "cifar10"), ("lfcW1A1", "mnist"), ("lfcW1A2", "mnist")):
@@ -18,8 +19,10 @@ for net, ds in (("cnvW1A1", "cifar10"), ("cnvW1A2", "cifar10"), ("cnvW2A2", "cif
     o = ol.Oracle(net, ol.param_dir(ds, net))
     kind = net[:3]
     sizes = edges[kind] + [int(x) for x in rng.integers(1, 1600 if kind == "cnv" else 5000, 12)]
-    if kind == "lfc":  # the one-launch block kernel's range (lfcW1A1: 4 097 .. 32 768 images)
-        sizes += [int(x) for x in rng.integers(4097, 34000, 10)]
+    if kind == "lfc":  # the one-launch block kernel's range (lfcW1A1: 4 097 .. 131 072 images)
+        sizes += [int(x) for x in rng.integers(4097, 34000, 10)] + [int(x) for x in rng.integers(34000, 131073, 4)] + [131071, 131072, 131073]
+    else:              # the tile form of layer 0 with ragged last blocks
+        sizes += [int(x) for x in rng.integers(8192, 20000, 4)]
     for n in sizes:
         imgs = rng.integers(0, 256, (n, N.isz), dtype=np.uint8)
         if rng.random() < 0.3:
@@ -33,4 +36,24 @@ for net, ds in (("cnvW1A1", "cifar10"), ("cnvW1A2", "cifar10"), ("cnvW2A2", "cif
         torch.cuda.synchronize()
         assert (cls.cpu().numpy() == o.classes_batched(imgs, 10)).all(), (net, n, "device classes")
     print(net, "ok:", len(sizes), "sizes", flush=True)
+# the file entry point either side of the size from which worker threads feed a ring of pinned pieces (24 MB), odd counts
+import ctypes as C, tempfile
+for net, ds, rec, nn in (("cnvW1A1", "cifar10", 3073, [7809, 7811, 8200, 9999, 12345, 33001, 70003]), ("lfcW1A1", "mnist", 784, [30000, 32101, 40001, 100003])):
+    N = gl.Net(net, ds)
+    o = ol.Oracle(net, ol.param_dir(ds, net))
+    for n in nn:
+        imgs = rng.integers(0, 256, (n, N.isz), dtype=np.uint8)
+        with tempfile.NamedTemporaryFile(dir="/tmp", suffix=".bin") as f:
+            if rec == 3073:
+                r = np.empty((n, 3073), np.uint8); r[:, 0] = 7; r[:, 1:] = imgs; f.write(r.tobytes())
+            else:
+                f.write((0x803).to_bytes(4, "big") + n.to_bytes(4, "big") + (28).to_bytes(4, "big") * 2 + imgs.tobytes())
+            f.flush()
+            cnt = C.c_int(0)
+            p = N.L.inference_multiple(f.name.encode(), 10, C.byref(cnt), None, 0)
+            assert p and cnt.value == n, (net, n)
+            got = np.ctypeslib.as_array(p, (n,)).copy()
+            N.L.free_results(p)
+        assert (got == o.classes_batched(imgs, 10)).all(), (net, n, "file classes")
+    print(net, "files ok:", nn, flush=True)
 print("fuzz ok")
