@@ -13,7 +13,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import gpu_lib as gl  # noqa: E402
 
 G = os.path.join(ROOT, "tests", "golden")
-for network, dataset, f in (("cnvW1A1", "cifar10", "deer.cifar"), ("cnvW2A2", "cifar10", "deer.cifar"), ("lfcW1A1", "mnist", "3.image-idx3-ubyte")):
+only = sys.argv[1:]   # optional: the networks to time
+for network, dataset, f in (("cnvW1A1", "cifar10", "deer.cifar"), ("cnvW2A2", "cifar10", "deer.cifar"), ("lfcW1A1", "mnist", "3.image-idx3-ubyte"),
+                            ("lfcW1A2", "mnist", "3.image-idx3-ubyte")):
+    if only and network not in only:
+        continue
     net = gl.Net(network, dataset)
     devnull = os.open(os.devnull, os.O_WRONLY)
     saved = os.dup(1)

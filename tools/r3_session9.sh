@@ -7,13 +7,13 @@ mkdir -p $O
 cd $R
 V=$R/bnn-pynq_amd/build/variants
 for rep in 1 2 3; do
-  python3 tools/latency.py 2>&1 | grep lfcW1A1 >> $O/latency_ab.txt
-  BNN_MI355X_LIBDIR=$V/noallrows python3 tools/latency.py 2>&1 | grep lfcW1A1 | sed 's/^/noallrows /' >> $O/latency_ab.txt
+  python3 tools/latency.py lfcW1A1 2>&1 | grep lfcW1A1 >> $O/latency_ab.txt
+  BNN_MI355X_LIBDIR=$V/noallrows python3 tools/latency.py lfcW1A1 2>&1 | grep lfcW1A1 | sed 's/^/noallrows /' >> $O/latency_ab.txt
 done
 cat $O/latency_ab.txt
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_a -- python3 $R/tools/latency.py > /dev/null 2>$O/kt_a.err
-BNN_MI355X_LIBDIR=$V/noallrows rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_b -- python3 $R/tools/latency.py > /dev/null 2>$O/kt_b.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_a -- python3 $R/tools/latency.py lfcW1A1 > /dev/null 2>$O/kt_a.err
+BNN_MI355X_LIBDIR=$V/noallrows rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_b -- python3 $R/tools/latency.py lfcW1A1 > /dev/null 2>$O/kt_b.err
 grep "lfc_fused<1>" $O/kt_a/*/*kernel_stats.csv | cut -c1-60,160-260; grep "lfc_fused<1>" $O/kt_b/*/*kernel_stats.csv | cut -c1-60,160-260
 cp $(ls $O/kt_a/*/*kernel_stats.csv | head -1) $O/kernel_stats_all_rows.csv; cp $(ls $O/kt_b/*/*kernel_stats.csv | head -1) $O/kernel_stats_two_rows.csv; rm -rf $O/kt_a $O/kt_b
 cd $R
