@@ -51,8 +51,8 @@ typedef const uint64_t __attribute__((address_space(4))) *kptr64;
 
 constexpr int kBlock = 256;
 constexpr int kLfcFusedMaxA2 = 2048;  // images: up to here lfcW1A2's one-launch kernel beats the six staged ones (tools/batch_sweep.py)
-#ifndef BNN_LFC_ALL_ROWS  // A/B builds: 0 = two weight rows in flight also for a single image
-#define BNN_LFC_ALL_ROWS 1
+#ifndef BNN_LFC_ALL_ROWS  // A/B builds: 1 = a single image requests the rows of all three big layers at entry
+#define BNN_LFC_ALL_ROWS 0
 #endif
 
 // Block -> (work-item block, neuron group), XCD-aware.  The `groups` blocks that evaluate
@@ -1579,9 +1579,10 @@ __global__ __launch_bounds__(1024) void k_lfc_fused(const uint8_t *__restrict__ 
   // A row, once in VGPRs, serves all IPB images of the block.
   uint64_t w0[13], w1[16], w2[16], w3[16];
   int t0, t1, t2, t3 = 0;
-  // A single image is pure latency: four dependent layers behind one trip to L2 each.  With one image per block the
-  // rows of ALL layers are requested at entry (90 dwords per thread: the block has the CU to itself, 128 VGPRs);
-  // with more images per block two rows are in flight at a time (more would spill at two blocks per CU).
+  // Two rows are in flight at a time.  (For a single image per block, requesting the rows of ALL three big layers at
+  // entry -- 90 dwords per thread, 118 VGPRs -- was built and measured, BNN_LFC_ALL_ROWS=1: the kernel trace shows
+  // 10.1 us against 8.0 and inference() reports 9.5 against 9.0: one CU takes 377 KB through its 64 B/clk port in
+  // 2.4 us either way, and all at once nothing of it hides behind a layer's evaluation.)
   constexpr bool ALL_ROWS = IPB == 1 && BNN_LFC_ALL_ROWS;
   // the pixels are requested first: vector loads return in order, so waiting for them must not mean waiting for rows
   uint8_t px[IPB];
@@ -1916,12 +1917,13 @@ __global__ __launch_bounds__(kBlock) void k_lfc_decode(const uint64_t *__restric
 // of one pass (profiles/r03_lfc_block_priorities.txt, us per batch, block vs staged): 32 768 images 161 vs 175,
 // 49 152 219 vs 239, 65 536 286 vs 304, 98 304 425 vs 438, 131 072 565 vs 572.  BNN_MI355X_LFC_BLOCK_MAX overrides
 // (tools/batch_sweep.py); the staged kernels remain what per-stage profiling and the stage-output test hook run.
-// images: up to here lfcW1A1 runs as k_lfc_fused<IPB> (a block per 1/2/4/8 images), beyond as k_lfc_block_s;
-// BNN_MI355X_LFC_FUSED_MAX overrides (tools/batch_sweep.py)
+// images: up to here lfcW1A1 runs as k_lfc_fused<IPB> (a block per 1/2/4 images), beyond as k_lfc_block_s -- measured
+// (profiles/r03_lfc_fused_vs_block.txt, us per batch, fused vs block): 513 images 15.5 vs 16.5, 1 024 16.1 vs 17.9,
+// 1 025 22.8 vs 18.2, 2 048 22.9 vs 19.1, 4 096 39.5 vs 25.7.  BNN_MI355X_LFC_FUSED_MAX overrides (tools/batch_sweep.py)
 inline long long lfc_fused_max() {
   static const long long v = [] {
     const char *e = std::getenv("BNN_MI355X_LFC_FUSED_MAX");
-    return e ? std::atoll(e) : 4096LL;
+    return e ? std::atoll(e) : 1024LL;
   }();
   return v;
 }

@@ -274,9 +274,9 @@ def test_device_api_crosses_the_chunk_boundary():
 @pytest.mark.parametrize("network", ["lfcW1A1", "lfcW1A2"])
 @pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 128, 129, 256, 257, 511, 512, 513, 1023, 1025, 2047, 2048, 2049, 4093, 4096, 4097])
 def test_lfc_small_batches_take_the_fused_kernel(network, n):
-    """<= 4096 (lfcW1A2: 2048) images: the LFC nets run as one launch, a block per group of 1/2/4/8 images (k_lfc_fused<IPB>,
-    k_lfc_fused_a2<IPB>); sizes either side of every policy edge, ragged last groups included; 4097 takes
-    the staged path"""
+    """<= 1024 (lfcW1A2: 2048) images: the LFC nets run as one launch, a block per group of 1/2/4/8 images (k_lfc_fused<IPB>,
+    k_lfc_fused_a2<IPB>); sizes either side of every policy edge, ragged last groups included; beyond, lfcW1A1 takes
+    k_lfc_block_s (1025 images: three per block) and lfcW1A2 the staged path"""
     import torch
     net = gpu_net(network, "mnist")
     o = oracle(network, "mnist")
@@ -602,9 +602,9 @@ def test_device_calls_on_two_streams_share_the_workspace_safely():
     assert (net.classify(batches[1][:200], 10) == o.classes_batched(batches[1][:200], 10)).all()   # still loaded
 
 
-@pytest.mark.parametrize("n", [4097, 4351, 4352, 5000, 10000, 16383, 32768, 32769, 70000])
+@pytest.mark.parametrize("n", [1025, 1537, 2048, 3001, 4097, 4351, 4352, 5000, 10000, 16383, 32768, 32769, 70000])
 def test_lfc_mid_batches_take_the_block_kernel(n):
-    """lfcW1A1 beyond the one-launch small-batch kernel (<= 4096 images), up to one pass of 131 072 images:
+    """lfcW1A1 beyond the one-launch small-batch kernel (<= 1024 images), up to one pass of 131 072 images:
     one k_lfc_block_s launch, a 1024-thread block per ceil(n / 512) images walking all four layers with the
     activations fed through SGPRs (BASELINE config 2 is 10 000 images).  Sizes either side of the policy edges,
     ragged last blocks, raw words through the host path and classes through the device path."""
