@@ -5,6 +5,10 @@ set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/final3
 mkdir -p $O
+cd $R
+timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > $O/tests.log 2>&1 || { tail -30 $O/tests.log; exit 1; }
+tail -2 $O/tests.log
+python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v "^Setting" | tail -3
 cd /tmp && export TMPDIR=/tmp
 # 1. HBM traffic of the final kernels (two PMC passes, no load-time warm-up: its small launches of the same kernels would
 #    be averaged in), then traffic.json, which the bench line quotes per stage
@@ -49,6 +53,9 @@ python3 bench.py --gpus 2 --steps 2 --warmup 1 > $O/bench_gpus2_on_one_gpu.json 
 set -e
 python3 bench.py --gpus 4 --rehearse-gloo --steps 5 --warmup 2 2>/dev/null | tail -1 > $O/rehearse_gloo_4_plain_start.json
 python3 bench.py --dist-world1 --steps 5 --warmup 2 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 > $O/rccl_world1.json
+# (the same two-rank rehearsal under a launcher, as the bench contract words it)
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --rehearse-gloo --steps 3 --warmup 1 2>/dev/null | tail -1 > $O/rehearse_gloo_2_torchrun.json
+tail -c 300 $O/rehearse_gloo_2_torchrun.json; echo
 # 7. host paths and sweeps on the final build
 python3 tools/path_rates.py cnvW1A1 131072 7 2>/dev/null | grep -v Setting > $O/path_rates.txt
 python3 tools/path_rates.py cnvW1A1 1048576 3 2>/dev/null | grep -v Setting >> $O/path_rates.txt
