@@ -51,9 +51,6 @@ typedef const uint64_t __attribute__((address_space(4))) *kptr64;
 
 constexpr int kBlock = 256;
 constexpr int kLfcFusedMaxA2 = 2048;  // images: up to here lfcW1A2's one-launch kernel beats the six staged ones (tools/batch_sweep.py)
-#ifndef BNN_LFC_ALL_ROWS  // A/B builds: 1 = a single image requests the rows of all three big layers at entry
-#define BNN_LFC_ALL_ROWS 0
-#endif
 
 // Block -> (work-item block, neuron group), XCD-aware.  The `groups` blocks that evaluate
 // different 32-neuron groups for the SAME 256 work items read the same input windows and write
@@ -1485,8 +1482,7 @@ __global__ __launch_bounds__(1024) void k_lfc_fused_a2(const uint8_t *__restrict
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, img0 = blockIdx.x * IPB;
   uint64_t w0[13], w1[16], w2[16], w3[16];
   int a0, b0, a1, b1, a2, b2, a3 = 0, b3 = 0;
-  // (pixels first, all three big rows at entry for a single image: see k_lfc_fused)
-  constexpr bool ALL_ROWS = IPB == 1 && BNN_LFC_ALL_ROWS;
+  // (pixels first: see k_lfc_fused)
   uint8_t px[IPB];
 #pragma unroll
   for (int i = 0; i < IPB; i++) {
@@ -1494,16 +1490,12 @@ __global__ __launch_bounds__(1024) void k_lfc_fused_a2(const uint8_t *__restrict
     px[i] = imgs[(size_t)img * 784 + (t < 784 ? t : 783)];
   }
   lfc_load_row2<13>(r0, t, w0, a0, b0);
-  if constexpr (ALL_ROWS) {
-    lfc_load_row2<16>(r1, t, w1, a1, b1);
-    lfc_load_row2<16>(r2, t, w2, a2, b2);
-  }
 #pragma unroll
   for (int i = 0; i < IPB; i++) {
     const uint64_t word = __ballot(px[i] >= 128 && t < 784);
     if (lane == 0) in0[i][wave] = word;
   }
-  if constexpr (!ALL_ROWS) lfc_load_row2<16>(r1, t, w1, a1, b1);
+  lfc_load_row2<16>(r1, t, w1, a1, b1);
   __syncthreads();
   // layer 0: XNOR inner product, two thresholds (pre-transformed: fire_i <=> m < t_i)
 #pragma unroll
@@ -1514,8 +1506,7 @@ __global__ __launch_bounds__(1024) void k_lfc_fused_a2(const uint8_t *__restrict
     const uint64_t f0 = __ballot(m < a0), f1 = __ballot(m < b0);
     if (lane == 0) { sg[0][i][wave] = ~(f0 | f1); nzp[0][i][wave] = ~(f0 ^ f1); }
   }
-  if constexpr (!ALL_ROWS) lfc_load_row2<16>(r2, t, w2, a2, b2);
-  else if (wave == 0) lfc_load_row2<16>(r3, lane, w3, a3, b3);
+  lfc_load_row2<16>(r2, t, w2, a2, b2);
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < IPB; i++) {
@@ -1523,9 +1514,7 @@ __global__ __launch_bounds__(1024) void k_lfc_fused_a2(const uint8_t *__restrict
     const uint64_t f0 = __ballot(q + a1 < 0), f1 = __ballot(q + b1 < 0);
     if (lane == 0) { sg[1][i][wave] = ~(f0 | f1); nzp[1][i][wave] = ~(f0 ^ f1); }
   }
-  if constexpr (!ALL_ROWS) {
-    if (wave == 0) lfc_load_row2<16>(r3, lane, w3, a3, b3);
-  }
+  if (wave == 0) lfc_load_row2<16>(r3, lane, w3, a3, b3);
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < IPB; i++) {
@@ -1580,10 +1569,9 @@ __global__ __launch_bounds__(1024) void k_lfc_fused(const uint8_t *__restrict__ 
   uint64_t w0[13], w1[16], w2[16], w3[16];
   int t0, t1, t2, t3 = 0;
   // Two rows are in flight at a time.  (For a single image per block, requesting the rows of ALL three big layers at
-  // entry -- 90 dwords per thread, 118 VGPRs -- was built and measured, BNN_LFC_ALL_ROWS=1: the kernel trace shows
-  // 10.1 us against 8.0 and inference() reports 9.5 against 9.0: one CU takes 377 KB through its 64 B/clk port in
-  // 2.4 us either way, and all at once nothing of it hides behind a layer's evaluation.)
-  constexpr bool ALL_ROWS = IPB == 1 && BNN_LFC_ALL_ROWS;
+  // entry -- 90 dwords per thread, 118 VGPRs -- was built and measured in round 3: the kernel trace shows 10.1 us
+  // against 8.0 and inference() reports 9.5 against 9.0: one CU takes 377 KB through its 64 B/clk port in 2.4 us
+  // either way, and all at once nothing of it hides behind a layer's evaluation.  profiles/r03_latency_all_rows_ab.txt)
   // the pixels are requested first: vector loads return in order, so waiting for them does not mean waiting for rows
   // (against the round-2 order -- row 0, then the pixels behind a branch -- no measurable difference: 8.7-9.3 vs 8.8-9.1 us)
   uint8_t px[IPB];
@@ -1593,34 +1581,27 @@ __global__ __launch_bounds__(1024) void k_lfc_fused(const uint8_t *__restrict__ 
     px[i] = imgs[(size_t)img * 784 + (t < 784 ? t : 783)];  // (unconditional: a branch would put the wait in front of the row loads)
   }
   lfc_load_row<13>(r0, t, w0, t0);
-  if constexpr (ALL_ROWS) {
-    lfc_load_row<16>(r1, t, w1, t1);
-    lfc_load_row<16>(r2, t, w2, t2);   // (layer 3's row -- wave 0 only -- takes layer 0's registers once they are free)
-  }
   // binarizeAndPack: bit i = (pixel i >= 128); pixels 784..831 are padding (0)
 #pragma unroll
   for (int i = 0; i < IPB; i++) {
     const uint64_t word = __ballot(px[i] >= 128 && t < 784);
     if (lane == 0) act[0][i][wave] = word;  // waves 13..15 write zeros
   }
-  if constexpr (!ALL_ROWS) lfc_load_row<16>(r1, t, w1, t1);
+  lfc_load_row<16>(r1, t, w1, t1);
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < IPB; i++) {
     const uint64_t word = __ballot(lfc_fires<13>(w0, t0, act[0][i]));
     if (lane == 0) act[1][i][wave] = word;
   }
-  if constexpr (!ALL_ROWS) lfc_load_row<16>(r2, t, w2, t2);
-  else if (wave == 0) lfc_load_row<16>(r3, lane, w3, t3);
+  lfc_load_row<16>(r2, t, w2, t2);
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < IPB; i++) {
     const uint64_t word = __ballot(lfc_fires<16>(w1, t1, act[1][i]));
     if (lane == 0) act[0][i][wave] = word;
   }
-  if constexpr (!ALL_ROWS) {
-    if (wave == 0) lfc_load_row<16>(r3, lane, w3, t3);
-  }
+  if (wave == 0) lfc_load_row<16>(r3, lane, w3, t3);
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < IPB; i++) {
@@ -1675,9 +1656,6 @@ __device__ __forceinline__ void lfc_row_regs(const uint32_t *__restrict__ rows, 
     wh[k] = v.y;
   }
 }
-#ifndef BNN_LFC_CHAINS
-#define BNN_LFC_CHAINS 1
-#endif
 
 #ifdef BNN_LFC_STAMPS
 // diagnostic build only (tools/build_variant.sh ... -DBNN_LFC_STAMPS): wave 0 of every block of k_lfc_block_s writes the
@@ -1724,18 +1702,6 @@ __device__ __forceinline__ int lfc_neuron_s(const uint32_t (&wl)[N], const uint3
                                             uint32_t &t) {
   auto word = [&](int d) { return d < 16 ? lo[d] : hi[d - 16]; };
   int m;
-#if BNN_LFC_CHAINS == 2
-  // diagnostic / A-B build: two accumulator chains (low and high dwords), one add at the end
-  int m2;
-  asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %4" : "+v"(t), "=v"(m) : "s"(word(0)), "v"(wl[0]), "v"(nt));
-  asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, 0" : "+v"(t), "=v"(m2) : "s"(word(1)), "v"(wh[0]));
-#pragma unroll
-  for (int k = 1; k < KW; k++) {
-    asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "+v"(t), "+v"(m) : "s"(word(2 * k)), "v"(wl[k]));
-    asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "+v"(t), "+v"(m2) : "s"(word(2 * k + 1)), "v"(wh[k]));
-  }
-  return m + m2;
-#else
   asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %4" : "+v"(t), "=v"(m) : "s"(word(0)), "v"(wl[0]), "v"(nt));
   asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "+v"(t), "+v"(m) : "s"(word(1)), "v"(wh[0]));
 #pragma unroll
@@ -1744,7 +1710,6 @@ __device__ __forceinline__ int lfc_neuron_s(const uint32_t (&wl)[N], const uint3
     asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "+v"(t), "+v"(m) : "s"(word(2 * k + 1)), "v"(wh[k]));
   }
   return m;
-#endif
 }
 
 #pragma clang diagnostic push
@@ -1764,10 +1729,10 @@ __device__ __forceinline__ void park_word(int &lo, int &hi, uint64_t word, int i
 // compiler sinks the loads behind the barrier all the same -- and rightly so: the wave that arrives last, the one
 // the barrier waits for, could not have issued them any earlier, its registers hold the current row until then.  Only
 // layer 0's row, requested at kernel entry, has its trip to L2 -- 1.3-2 us, per-wave clock stamps -- hidden.)
-template <int KW, int NKW, int MIDPRIO = -1>
+template <int KW, int NKW>
 __device__ __forceinline__ void lfc_block_layer_s(const uint32_t *__restrict__ next_rows, int next_neuron, uint32_t (&wl)[16], uint32_t (&wh)[16],
                                                   int &nt, const uint64_t *in, uint64_t *out, int cnt, int wave, int lane, uint32_t &t,
-                                                  int stamp = 0, int switch_at = -1) {
+                                                  int stamp = 0) {
   LFC_WSTAMP(stamp);
   v16u a_lo, a_hi;
   for (int base = 0; base < cnt; base += 64) {
@@ -1780,11 +1745,6 @@ __device__ __forceinline__ void lfc_block_layer_s(const uint32_t *__restrict__ n
     // (Walking the images in an order rotated per wave -- so that an image's scalar-cache miss is paid by one wave
     // instead of all sixteen at once -- was measured: no change, 61.9 vs 61.6 us for 10 000 images.)
     for (int i = 0; i < m; i++) {
-#ifdef BNN_LFC_PRIO_QUARTER  // A/B build: the priority steps fall INSIDE the layers (at 3/4, 1/2, 1/4 of layers 0, 1, 2)
-      if constexpr (MIDPRIO >= 0) {
-        if (base + i == switch_at) LFC_PRIO(MIDPRIO);
-      }
-#endif
       sload_image(in + (size_t)(base + i) * 16, a_lo, a_hi);
       park_word(lo, hi, __ballot(lfc_neuron_s<KW, 16>(wl, wh, nt, a_lo, a_hi, t) < 0), i);
 #ifdef BNN_LFC_STAMPS
@@ -1846,18 +1806,6 @@ __global__ __launch_bounds__(1024, 2) void k_lfc_block_s(const uint8_t *__restri
   // So a wave's priority falls with the layer it is in: whichever block is behind goes first, the two stay within a
   // layer of each other and the SIMDs have eight waves to choose from until the end (10 000 images 62.0 -> 57.0 us).
   LFC_PRIO(3);
-#ifdef BNN_LFC_PRIO_QUARTER
-  lfc_block_layer_s<13, 16, 2>(r1, tid, wl, wh, nt, A, B, cnt, wave, lane, t, 3, (3 * cnt) >> 2);
-  LFC_STAMP(2);
-  lfc_block_handoff();
-  LFC_STAMP(3);
-  LFC_WSTAMP(6);
-  lfc_block_layer_s<16, 16, 1>(r2, tid, wl, wh, nt, B, A, cnt, wave, lane, t, 7, cnt >> 1);
-  lfc_block_handoff();
-  LFC_STAMP(4);
-  LFC_WSTAMP(10);
-  lfc_block_layer_s<16, 16, 0>(r3, lane, wl, wh, nt, A, B, cnt, wave, lane, t, 11, cnt >> 2);
-#else
   lfc_block_layer_s<13, 16>(r1, tid, wl, wh, nt, A, B, cnt, wave, lane, t, 3);
   LFC_STAMP(2);
   lfc_block_handoff();
@@ -1870,7 +1818,6 @@ __global__ __launch_bounds__(1024, 2) void k_lfc_block_s(const uint8_t *__restri
   LFC_WSTAMP(10);
   LFC_PRIO(1);
   lfc_block_layer_s<16, 16>(r3, lane, wl, wh, nt, A, B, cnt, wave, lane, t, 11);  // (layer 3: 64 neurons, neuron = lane in every wave)
-#endif
   lfc_block_handoff();
   LFC_STAMP(5);
   LFC_WSTAMP(14);
