@@ -1678,37 +1678,25 @@ typedef uint32_t v16u __attribute__((ext_vector_type(16)));
 // A neuron's weight row in k_lfc_block_s: the 2 * KW weight dwords {lo_0, hi_0, lo_1, hi_1, ...} in eight 4-dword
 // registers, and the threshold dword.  It is REQUESTED with explicit load instructions (volatile asm: they stay where
 // they are written, the compiler would sink them to the first use) and is valid only behind the next
-// lfc_block_handoff(), whose s_waitcnt vmcnt(0) covers it.  The compiler does not know that the registers are still
-// being written: EVERY register a request names must stay allocated until the wait, or it is handed to other code
-// while the load is in flight (the first version loaded 28 dwords for KW = 13, two of them unused and therefore dead
-// for the compiler: the prologue got those two registers, the late load overwrote an address in them -- a GPU memory
-// fault in the warm-up).  Hence the tail of a KW = 13 row is a 2-dword load into a register pair of its own, and
-// lfc_row_arrived() -- the first reader, a volatile statement behind the hand-off -- names all of them as inputs.
+// lfc_block_handoff(), whose s_waitcnt vmcnt(0) covers it; nothing may touch it in between (lfc_row_arrived is the
+// first reader, a volatile statement behind the hand-off).  KW = 13 reads 2 dwords of the next row: harmless.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 struct LfcRow {
-  u32x4 q[8];   // KW = 16: all eight; KW = 13: q[0..5] and `tail`
-  u32x2 tail;
+  u32x4 q[8];
   uint32_t thr;
 };
 template <int KW>
 __device__ __forceinline__ void lfc_row_request(const uint32_t *rows, int n, LfcRow &w) {
-  static_assert(KW == 16 || KW == 13, "row shapes of the LFC layers");
   const uint32_t *r = rows + (size_t)n * (2 + 2 * KW);
   asm volatile("global_load_dword %0, %1, off" : "=v"(w.thr) : "v"(r) : "memory");
 #pragma unroll
-  for (int j = 0; j < KW / 2; j++)
+  for (int j = 0; j < (2 * KW + 3) / 4; j++)
     asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(w.q[j]) : "v"(r), "n"(8 + 16 * j) : "memory");
-  if constexpr (KW == 13) asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(w.tail) : "v"(r), "n"(8 + 16 * 6) : "memory");
 }
 // behind the hand-off: -t, the seed of every accumulator chain (the chain then ends on m - t)
-template <int KW>
 __device__ __forceinline__ int lfc_row_arrived(const LfcRow &w) {
   int nt;
-  if constexpr (KW == 16)
-    asm volatile("v_sub_u32 %0, 0, %1" : "=v"(nt) : "v"(w.thr), "v"(w.q[0]), "v"(w.q[1]), "v"(w.q[2]), "v"(w.q[3]), "v"(w.q[4]), "v"(w.q[5]), "v"(w.q[6]), "v"(w.q[7]));
-  else
-    asm volatile("v_sub_u32 %0, 0, %1" : "=v"(nt) : "v"(w.thr), "v"(w.q[0]), "v"(w.q[1]), "v"(w.q[2]), "v"(w.q[3]), "v"(w.q[4]), "v"(w.q[5]), "v"(w.tail));
+  asm volatile("v_sub_u32 %0, 0, %1" : "=v"(nt) : "v"(w.thr));
   return nt;
 }
 // Both loads AND their wait in one statement, early-clobber outputs: the compiler can neither place `lo` over the
@@ -1722,8 +1710,8 @@ __device__ __forceinline__ void sload_image(const uint64_t *p, v16u &lo, v16u &h
 template <int KW>
 __device__ __forceinline__ int lfc_neuron_s(const LfcRow &w, int nt, const v16u &lo, const v16u &hi, uint32_t &t) {
   auto word = [&](int d) { return d < 16 ? lo[d] : hi[d - 16]; };
-  auto wlo = [&](int k) { return (KW == 13 && k == 12) ? w.tail[0] : w.q[k >> 1][2 * (k & 1)]; };
-  auto whi = [&](int k) { return (KW == 13 && k == 12) ? w.tail[1] : w.q[k >> 1][2 * (k & 1) + 1]; };
+  auto wlo = [&](int k) { return w.q[k >> 1][2 * (k & 1)]; };
+  auto whi = [&](int k) { return w.q[k >> 1][2 * (k & 1) + 1]; };
   int m;
   asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %4" : "+v"(t), "=v"(m) : "s"(word(0)), "v"(wlo(0)), "v"(nt));
   asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "+v"(t), "+v"(m) : "s"(word(1)), "v"(whi(0)));
@@ -1756,7 +1744,7 @@ __device__ __forceinline__ void park_word(int &lo, int &hi, uint64_t word, int i
 template <int KW, int NKW>
 __device__ __forceinline__ void lfc_block_layer_s(const uint32_t *__restrict__ next_rows, int next_neuron, LfcRow &w, const uint64_t *in,
                                                   uint64_t *out, int cnt, int wave, int lane, uint32_t &t, int stamp = 0) {
-  const int nt = lfc_row_arrived<KW>(w);
+  const int nt = lfc_row_arrived(w);
   LFC_WSTAMP(stamp);
   v16u a_lo, a_hi;
   for (int base = 0; base < cnt; base += 64) {
@@ -1846,7 +1834,7 @@ __global__ __launch_bounds__(1024, 2) void k_lfc_block_s(const uint8_t *__restri
   LFC_WSTAMP(14);
   LFC_PRIO(0);
   {  // layer 3 + decode: the waves share out the images
-    const int nt = lfc_row_arrived<16>(w);
+    const int nt = lfc_row_arrived(w);
     v16u lo, hi;
     for (int i = wave; i < cnt; i += 16) {
       sload_image(B + (size_t)i * 16, lo, hi);

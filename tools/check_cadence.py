@@ -156,48 +156,6 @@ def check_loop(loop, logic_ops, pairs, other_valu, allowed=()):
             "pairs_followed_by_several_bubbles": long_bubbles, "problems": problems}
 
 
-def vregs(text):
-    """VGPR numbers named in an operand string"""
-    out = set()
-    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", text):
-        out |= set(range(int(a), int(b) + 1))
-    for a in re.findall(r"\bv(\d+)\b", text):
-        out.add(int(a))
-    return out
-
-
-def check_row_requests(body, expected_groups=4):
-    """k_lfc_block_s requests a weight row with explicit (inline-asm) global loads whose results are valid only behind
-    the next s_waitcnt vmcnt(0) + s_barrier -- which the compiler does not know.  Verify in the built code that between
-    each request (a global_load_dword with `off` addressing followed by global_load_dwordx4/x2) and the next s_barrier
-    NO instruction names any of the requested registers: otherwise a register with a load in flight has been handed to
-    other code (it happened once: two registers the compiler considered dead, a GPU memory fault)."""
-    ins = [(m, o) for lab, m, o in body if m]
-    problems, groups, i = [], 0, 0
-    while i < len(ins):
-        m, o = ins[i]
-        if m == "global_load_dword" and ", off" in o:
-            dst, j = set(), i
-            while j < len(ins) and (ins[j][0].startswith("global_load") or (ins[j][0].startswith("s_") and ins[j][0] != "s_waitcnt" and j - i < 40)):
-                if ins[j][0].startswith("global_load"):
-                    dst |= vregs(ins[j][1].split(",")[0])
-                    last = j
-                j += 1
-            k = last + 1
-            while k < len(ins) and ins[k][0] != "s_barrier":
-                if ins[k][0].startswith(("v_", "global_", "ds_", "flat_", "buffer_")) and vregs(ins[k][1]) & dst:
-                    problems.append("row register touched before the wait: %s %s" % ins[k])
-                k += 1
-            if k == len(ins):
-                problems.append("row request without a barrier behind it")
-            groups += 1
-            i = k
-        i += 1
-    if groups != expected_groups:
-        problems.append("%d row requests found, expected %d" % (groups, expected_groups))
-    return {"row_requests": groups, "problems": problems}
-
-
 def run(obj):
     fns = functions(disassemble(obj))
     report, ok = {}, True
@@ -217,10 +175,6 @@ def run(obj):
         r = check_loop(loops[0], logic_ops, pairs, other, rest[0] if rest else ())
         report[prefix] = r
         ok = ok and not r["problems"]
-        if prefix == "k_lfc_block_s":
-            rr = check_row_requests(fns[names[0]])
-            report[prefix + " (row requests)"] = rr
-            ok = ok and not rr["problems"]
     return ok, report
 
 
