@@ -1675,29 +1675,19 @@ __device__ unsigned long long g_lfc_wstamps[1024 * 16 * 16];
 #define LFC_PRIO(p) __builtin_amdgcn_s_setprio(p)
 #endif
 typedef uint32_t v16u __attribute__((ext_vector_type(16)));
-// A neuron's weight row in k_lfc_block_s: the 2 * KW weight dwords {lo_0, hi_0, lo_1, hi_1, ...} in eight 4-dword
-// registers, and the threshold dword.  It is REQUESTED with explicit load instructions (volatile asm: they stay where
-// they are written, the compiler would sink them to the first use) and is valid only behind the next
-// lfc_block_handoff(), whose s_waitcnt vmcnt(0) covers it; nothing may touch it in between (lfc_row_arrived is the
-// first reader, a volatile statement behind the hand-off).  KW = 13 reads 2 dwords of the next row: harmless.
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-struct LfcRow {
-  u32x4 q[8];
-  uint32_t thr;
-};
+// row `n` of a layer with KW input words into the first KW entries of (wl, wh)
 template <int KW>
-__device__ __forceinline__ void lfc_row_request(const uint32_t *rows, int n, LfcRow &w) {
-  const uint32_t *r = rows + (size_t)n * (2 + 2 * KW);
-  asm volatile("global_load_dword %0, %1, off" : "=v"(w.thr) : "v"(r) : "memory");
+__device__ __forceinline__ void lfc_row_regs16(const uint32_t *__restrict__ rows, int n, uint32_t (&wl)[16], uint32_t (&wh)[16], int &nt) {
+  constexpr int ROW_DW = 2 + 2 * KW;
+  const uint32_t *__restrict__ r = rows + (size_t)n * ROW_DW;
+  nt = -(int)r[0];
+  const uint2 *__restrict__ p = reinterpret_cast<const uint2 *>(r + 2);
 #pragma unroll
-  for (int j = 0; j < (2 * KW + 3) / 4; j++)
-    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(w.q[j]) : "v"(r), "n"(8 + 16 * j) : "memory");
-}
-// behind the hand-off: -t, the seed of every accumulator chain (the chain then ends on m - t)
-__device__ __forceinline__ int lfc_row_arrived(const LfcRow &w) {
-  int nt;
-  asm volatile("v_sub_u32 %0, 0, %1" : "=v"(nt) : "v"(w.thr));
-  return nt;
+  for (int k = 0; k < KW; k++) {
+    const uint2 v = p[k];
+    wl[k] = v.x;
+    wh[k] = v.y;
+  }
 }
 // Both loads AND their wait in one statement, early-clobber outputs: the compiler can neither place `lo` over the
 // address pair the second load still reads, nor copy / spill the tuples between the loads and the wait.
@@ -1707,18 +1697,17 @@ __device__ __forceinline__ void sload_image(const uint64_t *p, v16u &lo, v16u &h
 // m - t of this thread's neuron for one image (its 32 dwords in SGPRs).  (Two neurons per thread -- 4 * KW
 // pairs per scalar-load wait, 512-thread blocks -- was measured too: 3 % faster at 131 072 images, 10 % slower at
 // 10 000, where this kernel is used.)
-template <int KW>
-__device__ __forceinline__ int lfc_neuron_s(const LfcRow &w, int nt, const v16u &lo, const v16u &hi, uint32_t &t) {
+template <int KW, int N = KW>
+__device__ __forceinline__ int lfc_neuron_s(const uint32_t (&wl)[N], const uint32_t (&wh)[N], int nt, const v16u &lo, const v16u &hi,
+                                            uint32_t &t) {
   auto word = [&](int d) { return d < 16 ? lo[d] : hi[d - 16]; };
-  auto wlo = [&](int k) { return w.q[k >> 1][2 * (k & 1)]; };
-  auto whi = [&](int k) { return w.q[k >> 1][2 * (k & 1) + 1]; };
   int m;
-  asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %4" : "+v"(t), "=v"(m) : "s"(word(0)), "v"(wlo(0)), "v"(nt));
-  asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "+v"(t), "+v"(m) : "s"(word(1)), "v"(whi(0)));
+  asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %4" : "+v"(t), "=v"(m) : "s"(word(0)), "v"(wl[0]), "v"(nt));
+  asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "+v"(t), "+v"(m) : "s"(word(1)), "v"(wh[0]));
 #pragma unroll
   for (int k = 1; k < KW; k++) {
-    asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "+v"(t), "+v"(m) : "s"(word(2 * k)), "v"(wlo(k)));
-    asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "+v"(t), "+v"(m) : "s"(word(2 * k + 1)), "v"(whi(k)));
+    asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "+v"(t), "+v"(m) : "s"(word(2 * k)), "v"(wl[k]));
+    asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "+v"(t), "+v"(m) : "s"(word(2 * k + 1)), "v"(wh[k]));
   }
   return m;
 }
@@ -1734,17 +1723,16 @@ __device__ __forceinline__ void park_word(int &lo, int &hi, uint64_t word, int i
 }
 #pragma clang diagnostic pop
 
-// one layer over the block's cnt images: in / out = global maps [image][16] words (in: wave-uniform pointer).
-// The layer's weight row has arrived in `w` (requested before the hand-off in front of this layer); behind the last
-// image the row of the NEXT layer (NKW words, 0: none) is requested into the same registers, in front of the next
-// hand-off: a wave that reaches the barrier early has its row by the time the barrier opens -- only the waves that
-// arrive last still wait for theirs, and then there is work on the SIMD (per-wave clock stamps: the trip to L2 is
-// 1.3-2 us per layer, and with the compiler's placement -- behind the barrier, at the first use -- all sixteen waves
-// of the block sat it out together).
+// one layer over the block's cnt images: in / out = global maps [image][16] words (in: wave-uniform pointer)
+// The weight row of the layer is in (wl, wh, nt) on entry; on exit the row of the NEXT layer (NKW words, 0: none) has
+// been requested into the same registers.  (Written behind this layer's last pair, in front of the hand-off; the
+// compiler sinks the loads behind the barrier all the same -- and rightly so: the wave that arrives last, the one
+// the barrier waits for, could not have issued them any earlier, its registers hold the current row until then.  Only
+// layer 0's row, requested at kernel entry, has its trip to L2 -- 1.3-2 us, per-wave clock stamps -- hidden.)
 template <int KW, int NKW>
-__device__ __forceinline__ void lfc_block_layer_s(const uint32_t *__restrict__ next_rows, int next_neuron, LfcRow &w, const uint64_t *in,
-                                                  uint64_t *out, int cnt, int wave, int lane, uint32_t &t, int stamp = 0) {
-  const int nt = lfc_row_arrived(w);
+__device__ __forceinline__ void lfc_block_layer_s(const uint32_t *__restrict__ next_rows, int next_neuron, uint32_t (&wl)[16], uint32_t (&wh)[16],
+                                                  int &nt, const uint64_t *in, uint64_t *out, int cnt, int wave, int lane, uint32_t &t,
+                                                  int stamp = 0) {
   LFC_WSTAMP(stamp);
   v16u a_lo, a_hi;
   for (int base = 0; base < cnt; base += 64) {
@@ -1758,14 +1746,14 @@ __device__ __forceinline__ void lfc_block_layer_s(const uint32_t *__restrict__ n
     // instead of all sixteen at once -- was measured: no change, 61.9 vs 61.6 us for 10 000 images.)
     for (int i = 0; i < m; i++) {
       sload_image(in + (size_t)(base + i) * 16, a_lo, a_hi);
-      park_word(lo, hi, __ballot(lfc_neuron_s<KW>(w, nt, a_lo, a_hi, t) < 0), i);
+      park_word(lo, hi, __ballot(lfc_neuron_s<KW, 16>(wl, wh, nt, a_lo, a_hi, t) < 0), i);
 #ifdef BNN_LFC_STAMPS
       if (base == 0 && i == 0) LFC_WSTAMP(stamp + 1);
 #endif
     }
     if (lane < m) out[(size_t)(base + lane) * 16 + wave] = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
   }
-  if constexpr (NKW > 0) lfc_row_request<NKW>(next_rows, next_neuron, w);
+  if constexpr (NKW > 0) lfc_row_regs16<NKW>(next_rows, next_neuron, wl, wh, nt);
   LFC_WSTAMP(stamp + 2);
 }
 
@@ -1790,8 +1778,9 @@ __global__ __launch_bounds__(1024, 2) void k_lfc_block_s(const uint8_t *__restri
   uint32_t t = chain_temp();
   LFC_STAMP(0);
   LFC_WSTAMP(0);
-  LfcRow w;
-  lfc_row_request<13>(r0, tid, w);  // layer 0's row: its trip to L2 runs behind the binarisation below
+  uint32_t wl[16], wh[16];
+  int nt;
+  lfc_row_regs16<13>(r0, tid, wl, wh, nt);  // layer 0's row: its trip to L2 runs behind the binarisation below
   // binarizeAndPack into A: one lane per output word (words 13..15 of an image are never read by layer 0)
   for (int idx = tid; idx < cnt * 16; idx += 1024) {
     const int i = idx >> 4, k = idx & 15;
@@ -1817,28 +1806,27 @@ __global__ __launch_bounds__(1024, 2) void k_lfc_block_s(const uint8_t *__restri
   // So a wave's priority falls with the layer it is in: whichever block is behind goes first, the two stay within a
   // layer of each other and the SIMDs have eight waves to choose from until the end (10 000 images 62.0 -> 57.0 us).
   LFC_PRIO(3);
-  lfc_block_layer_s<13, 16>(r1, tid, w, A, B, cnt, wave, lane, t, 3);
+  lfc_block_layer_s<13, 16>(r1, tid, wl, wh, nt, A, B, cnt, wave, lane, t, 3);
   LFC_STAMP(2);
   lfc_block_handoff();
   LFC_STAMP(3);
   LFC_WSTAMP(6);
   LFC_PRIO(2);
-  lfc_block_layer_s<16, 16>(r2, tid, w, B, A, cnt, wave, lane, t, 7);
+  lfc_block_layer_s<16, 16>(r2, tid, wl, wh, nt, B, A, cnt, wave, lane, t, 7);
   lfc_block_handoff();
   LFC_STAMP(4);
   LFC_WSTAMP(10);
   LFC_PRIO(1);
-  lfc_block_layer_s<16, 16>(r3, lane, w, A, B, cnt, wave, lane, t, 11);  // (layer 3: 64 neurons, neuron = lane in every wave)
+  lfc_block_layer_s<16, 16>(r3, lane, wl, wh, nt, A, B, cnt, wave, lane, t, 11);  // (layer 3: 64 neurons, neuron = lane in every wave)
   lfc_block_handoff();
   LFC_STAMP(5);
   LFC_WSTAMP(14);
   LFC_PRIO(0);
   {  // layer 3 + decode: the waves share out the images
-    const int nt = lfc_row_arrived(w);
     v16u lo, hi;
     for (int i = wave; i < cnt; i += 16) {
       sload_image(B + (size_t)i * 16, lo, hi);
-      const uint64_t word = __ballot(lfc_neuron_s<16>(w, nt, lo, hi, t) < 0);
+      const uint64_t word = __ballot(lfc_neuron_s<16, 16>(wl, wh, nt, lo, hi, t) < 0);
       if (lane == 0) {
         words[img0 + i] = word;
         if (classes) {
