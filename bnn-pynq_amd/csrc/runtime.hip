@@ -16,6 +16,9 @@
 #include <hip/hip_runtime.h>
 
 #include <fcntl.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <sys/stat.h>
 #include <sched.h>
 #include <unistd.h>
@@ -61,18 +64,19 @@ constexpr int kHeadChunk = 2048;   // ... the first chunk: what the stages wait 
 
 // Chunk boundaries of a host-buffer / file call: base[c] .. base[c+1] are the images of chunk c.
 // The pipeline is copy | stages, double buffered.  With equal chunks the first copy (32 768 CIFAR records =
-// 100 MB: ~3 ms of pread + H2D) runs with the GPU idle, so the chunks ramp up from 2 048 images -- by a factor that
-// keeps the NEXT chunk's transfer shorter than THIS chunk's stages, or the stages starve at every step of the ramp
-// (measured with a device timeline, profiles/r03_host_path_timelines.txt: doubling left 0.3-0.8 ms holes):
-//   * a buffer in host memory arrives at 54 GB/s = 17.6 M CIFAR images/s against 12.5 M/s of stages: x1.5 per
-//     step; the call is compute-bound, its end is the last chunk's stages whatever their size: no ramp down;
-//   * a file arrives at ~35 GB/s (pread from the page cache + DMA), a little slower than the stages: x1.25, and the
-//     chunks ramp down again towards the end (what follows the last byte is the last chunk's stages).
+// 100 MB: ~3 ms of pread + H2D) runs with the GPU idle, so the chunks ramp up -- by a factor that keeps the NEXT
+// chunk's transfer about as long as THIS chunk's stages, or the stages starve at every step of the ramp (measured with
+// a device timeline, profiles/r03_host_path_timelines.txt: doubling left 0.3-0.8 ms holes).  Both sources now arrive
+// faster than the stages consume them (a buffer in host memory at 54 GB/s = 17.6 M CIFAR images/s, a file through the
+// pinned ring and two DMA queues at ~46 GB/s = 15 M/s, against 12.5 M/s of stages), so a call is compute-bound: what ends
+// it is the last chunk's stages whatever their size -- no ramp down -- and small chunks cost stage efficiency (2 048 images
+// run at 9.7 M/s, 32 768 at 12.1): x1.5 per step from 2 048 (buffer) / 4 096 (file) images up to 32 768
+// (profiles/r03_chunk_plan_sweep.txt, r03_file_path_two_queues_plan_sweep.txt).
 // BNN_MI355X_CHUNKS=head:tail:max[:growth%] overrides the sizes (0 = no ramp at that end; tuning / A-B runs).
 std::vector<int> plan_chunks(int n, bool single, bool from_file) {
   // (sizes are tuned in bytes on CIFAR records: an MNIST image is a quarter of one)
   const int scale = net_spec(BNN_NETWORK).is_cnv ? 1 : 4;
-  int head = kHeadChunk * scale, tail = from_file ? kHeadChunk * scale : 0, big = kHostChunk, growth = from_file ? 125 : 150;
+  int head = (from_file ? 2 : 1) * kHeadChunk * scale, tail = 0, big = kHostChunk, growth = 150;
   if (const char *e = std::getenv("BNN_MI355X_CHUNKS")) {
     int h = 0, t = 0, b = 0, g = growth;
     const int got = std::sscanf(e, "%d:%d:%d:%d", &h, &t, &b, &g);
@@ -101,6 +105,11 @@ std::vector<int> plan_chunks(int n, bool single, bool from_file) {
       rem -= t;
       sb = grow(sb);
     }
+  }
+  // a small remainder joins the chunk in front of it (a chunk of a few hundred images costs nine launches all the same)
+  if (back.empty() && front.size() >= 2 && front.back() * 2 < front[front.size() - 2] && front.back() + front[front.size() - 2] <= kHostChunk) {
+    front[front.size() - 2] += front.back();
+    front.pop_back();
   }
   std::vector<int> base;
   base.push_back(0);
@@ -433,6 +442,14 @@ int usable_cpus() {
   return n > 0 ? n : 1;
 }
 
+#if defined(__x86_64__)
+// write the lines of [p, p + n) back to memory and drop them from the caches (clflushopt: unordered, one fence at the end)
+__attribute__((target("clflushopt"))) void flush_lines(const uint8_t *p, size_t n) {
+  for (size_t i = 0; i < n; i += 64) _mm_clflushopt(const_cast<uint8_t *>(p) + i);
+  _mm_sfence();
+}
+#endif
+
 struct Feeder {
   static constexpr int kSlots = 12;
   size_t kSlotBytes = 4u << 20;  // BNN_MI355X_FEEDER_PIECE_MB overrides (tuning): alone, 4 MB pieces move at 49 GB/s, 8 MB at 52, 16 MB at 54
@@ -440,6 +457,13 @@ struct Feeder {
   struct Piece { int chunk; size_t off_in_chunk, src_off, bytes; bool last_of_chunk; };
   uint8_t *ring = nullptr;  // kSlots x kSlotBytes, pinned
   hipEvent_t sent[kSlots] = {};
+  // Two things make the pipe faster than "pread, then one DMA queue" (tools/file_pipe_probe.cpp, profiles/r03_file_pipe_probe.txt:
+  // 33-37 GB/s): the pieces alternate over TWO streams, i.e. two DMA queues (46 GB/s), and the readers write their lines
+  // back behind the pread (clflushopt: a DMA that finds the lines dirty in a core's cache runs at two thirds of its rate;
+  // 43 GB/s on one queue).  BNN_MI355X_FEEDER_STREAMS / BNN_MI355X_FEEDER_FLUSH override.
+  hipStream_t aux = nullptr;
+  hipEvent_t aux_done = nullptr;
+  bool flush = false;
   std::vector<std::thread> workers;
   std::mutex mu;
   std::condition_variable cv_job, cv_done;
@@ -463,6 +487,9 @@ struct Feeder {
       if (got <= 0) return false;
       done += (size_t)got;
     }
+#if defined(__x86_64__)
+    if (flush) flush_lines(dst, pc.bytes);
+#endif
     return true;
   }
   void worker() {
@@ -496,6 +523,14 @@ struct Feeder {
     if (hipHostMalloc(reinterpret_cast<void **>(&ring), kSlots * kSlotBytes, hipHostMallocDefault) != hipSuccess) { ring = nullptr; return -1; }
     for (auto &e : sent)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -1;
+    const char *es = std::getenv("BNN_MI355X_FEEDER_STREAMS"), *ef = std::getenv("BNN_MI355X_FEEDER_FLUSH");
+    if (!es || std::atoi(es) == 2) {
+      if (hipStreamCreateWithFlags(&aux, hipStreamNonBlocking) != hipSuccess) return -1;
+      if (hipEventCreateWithFlags(&aux_done, hipEventDisableTiming) != hipSuccess) return -1;
+    }
+#if defined(__x86_64__)
+    flush = (ef ? std::atoi(ef) != 0 : false) && __builtin_cpu_supports("clflushopt");
+#endif
     // Readers: 4 pread() threads already move 45 GB/s out of the page cache (8: 74 GB/s), more than the link takes;
     // beyond ~6 the DMA, which reads the lines they have just written, slows down more than they speed up
     // (profiles/r03_file_path_sweep.txt: 2 threads 20.4 ms per 131 072-record file, 4: 12.9-14.7, 6: 14.1, 14: 14.2).
@@ -591,14 +626,22 @@ int feed_chunks(const uint8_t *mem, int fd, size_t first, size_t rec, size_t ski
     }
     uint8_t *chunk_dst = skip ? r.d_rec[slot] : r.d_images[slot];
     // the chunk buffer of two chunks ago: its stages (no label bytes) / its strip kernel (same stream: in order) are done
-    if (!skip && pc.off_in_chunk == 0 && c >= 2) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));
-    // (Odd pieces through a second stream -- a second DMA queue -- was measured: no gain, 13.7 vs 12.9 ms per file.)
-    HIP_OK(hipMemcpyAsync(chunk_dst + pc.off_in_chunk, F.ring + (p % Feeder::kSlots) * F.kSlotBytes, pc.bytes, hipMemcpyHostToDevice,
-                          r.copy_stream));
-    HIP_OK(hipEventRecord(F.sent[p % Feeder::kSlots], r.copy_stream));
+    if (pc.off_in_chunk == 0 && c >= 2) {
+      if (!skip) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));
+      // (the second queue writes the same chunk buffer: behind chunk c-2's stages, or -- label bytes -- behind its strip
+      // kernel, after which `copied` was recorded)
+      if (F.aux) HIP_OK(hipStreamWaitEvent(F.aux, skip ? r.copied[slot] : r.consumed[slot], 0));
+    }
+    hipStream_t ds = (F.aux && (p & 1)) ? F.aux : r.copy_stream;
+    HIP_OK(hipMemcpyAsync(chunk_dst + pc.off_in_chunk, F.ring + (p % Feeder::kSlots) * F.kSlotBytes, pc.bytes, hipMemcpyHostToDevice, ds));
+    HIP_OK(hipEventRecord(F.sent[p % Feeder::kSlots], ds));
     issued = p + 1;
     release_done();
     if (!pc.last_of_chunk) continue;
+    if (F.aux) {  // the chunk is complete when both queues have delivered their pieces
+      HIP_OK(hipEventRecord(F.aux_done, F.aux));
+      HIP_OK(hipStreamWaitEvent(r.copy_stream, F.aux_done, 0));
+    }
     const int base = plan[c], m = plan[c + 1] - plan[c];
     if (skip) {
       if (c >= 2) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));  // d_images[slot] free again

@@ -144,12 +144,11 @@ int bnn_mi355x_inference_device(const void *d_images, int n_images, int number_c
 int bnn_mi355x_reserve(int max_images);
 
 /* How the entry points that take HOST data cut a call of n images into chunks whose transfer overlaps the
- * previous chunk's stages -- from_file != 0: inference_multiple(path) (the chunks ramp up x1.25 from 2 048 images
- * and down again at the end: the file arrives a little slower than the stages run); from_file == 0:
- * inference_buffer / inference_raw (x1.5 up, no ramp down: host memory arrives faster than the stages).  Writes
- * the chunk boundaries base[0] = 0 < base[1] < ... < base[k] = n (at most cap of them) and returns k + 1; no chunk
- * holds more than 32 768 images.  Host only; results never depend on the plan (tests/test_gpu_parity.py walks
- * its edges). */
+ * previous chunk's stages: small chunks first (the first transfer is what nothing overlaps), each 1.5 times the one
+ * before, up to 32 768 images; from_file != 0: inference_multiple(path), which starts at 4 096 images, from_file == 0:
+ * inference_buffer / inference_raw, which start at 2 048 (MNIST images: four times as many).  Writes the chunk
+ * boundaries base[0] = 0 < base[1] < ... < base[k] = n (at most cap of them) and returns k + 1.  Host only; results never
+ * depend on the plan (tests/test_gpu_parity.py walks its edges). */
 int bnn_mi355x_chunk_plan(int n_images, int from_file, int *bases, int cap);
 
 /* Fault campaigns: fix the seed of the fault planner (0 = std::random_device like the

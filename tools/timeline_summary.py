@@ -50,3 +50,19 @@ print("  largest gaps in the kernel stream (us, at ms, between):")
 for g in gaps[:8]:
     print("    %8.1f us at %.2f ms  %s -> %s" % (g[0] / 1e3, g[1], g[2], g[3]))
 print("  copies: " + " ".join("%s:%.2f-%.2f" % (c[3][:3], (c[0] - t0) / 1e6, (c[1] - t0) / 1e6) for c in Cc[:40]))
+
+# chunk view: every k_strip_records launch closes a chunk's transfer; list when it ran and when the chunk's last stage ended
+strips = [e for e in K if "strip" in e[3]]
+if strips:
+    print("  chunks (strip kernel start ms, next strip start ms, stage kernels busy between them ms):")
+    for i, sk in enumerate(strips):
+        nxt = strips[i + 1][0] if i + 1 < len(strips) else t1
+        print("    chunk %2d: transfer complete at %6.2f ms" % (i, (sk[0] - t0) / 1e6))
+    stage = [e for e in K if "strip" not in e[3]]
+    # idle gaps of the stage stream longer than 50 us
+    g = []
+    for a, b in zip(stage, stage[1:]):
+        if b[0] - a[1] > 50e3:
+            g.append(((a[1] - t0) / 1e6, (b[0] - a[1]) / 1e3))
+    print("  stage-stream gaps > 50 us (at ms: us): " + " ".join("%.2f:%.0f" % x for x in g))
+    print("  sum of those gaps: %.2f ms; stages busy %.2f ms" % (sum(x[1] for x in g) / 1e3, union(stage) / 1e6))
