@@ -349,9 +349,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    tw = time.perf_counter()
     for _ in range(a.warmup):
         step()
     barrier()
+    # steps shorter than 2 ms (the LFC nets: 0.06-0.7 ms): W of them are over before the clocks have settled -- keep the
+    # GPU busy until 100 ms of untimed work have passed (never the case for the default workload: 10.5 ms per step)
+    if a.warmup and (time.perf_counter() - tw) / a.warmup < 2e-3:
+        while time.perf_counter() - tw < 0.1:
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize()
+        barrier()
     # HIP events around every stage, on the stream the kernels run on, inside the timed region -- where the dispatch policy IS
     # the staged form (the CNV nets above 32 768 images: the default 131 072).  Elsewhere the library may
     # run a network as ONE launch (k_lfc_block_s, k_lfc_fused, k_cnv_tail), which per-stage events would switch off: `value`
