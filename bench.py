@@ -353,9 +353,9 @@ def main():
     for _ in range(a.warmup):
         step()
     barrier()
-    # steps shorter than 2 ms (the LFC nets: 0.06-0.7 ms): W of them are over before the clocks have settled -- keep the
-    # GPU busy until 100 ms of untimed work have passed (never the case for the default workload: 10.5 ms per step)
-    if a.warmup and (time.perf_counter() - tw) / a.warmup < 2e-3:
+    # the LFC nets' steps take 0.06-0.7 ms: W of them are over before the clocks have settled -- keep the GPU busy until
+    # 100 ms of untimed work have passed (decided by the network, not by a timing: every rank takes the same branch)
+    if not is_cnv:
         while time.perf_counter() - tw < 0.1:
             for _ in range(20):
                 step()
