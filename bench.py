@@ -123,6 +123,8 @@ def self_launch(a, argv):
     rc, failed = 0, None
     live = set(range(a.gpus))
     deadline = None
+    give_up = time.time() + a.launch_timeout      # ranks that never come back (a rendezvous that hangs): a record, not silence
+    timed_out = False
     while live:
         for r in sorted(live):
             c = procs[r].poll()
@@ -132,13 +134,19 @@ def self_launch(a, argv):
             if c != 0 and rc == 0:
                 rc, failed = c, r
                 deadline = time.time() + 30.0     # the others hang in a collective without their peer: give them 30 s
+        if live and time.time() > give_up and not timed_out:
+            timed_out, deadline = True, time.time()
+            if rc == 0:
+                rc, failed = 124, min(live)
         if deadline and time.time() > deadline:
             for r in live:                        # exactly the processes started above, nothing by pattern
                 procs[r].kill()
         time.sleep(0.05)
     for t in threads:
         t.join(timeout=5)
-    if rc != 0 and not seen_json[0]:
+    if timed_out and not seen_json[0]:
+        error_line(a, "the %d ranks did not finish within %d s (rank %d still running): killed" % (a.gpus, a.launch_timeout, failed), returncode=rc)
+    elif rc != 0 and not seen_json[0]:
         error_line(a, "rank %d of %d exited with code %d before the result line was printed" % (failed, a.gpus, rc), returncode=rc)
     elif rc == 0 and not seen_json[0]:
         error_line(a, "all %d ranks exited 0 but none printed a result line" % a.gpus)
@@ -255,6 +263,9 @@ def parse_args(argv=None):
     ap.add_argument("--dist-world1", action="store_true",
                     help="run the multi-GPU code path (process group, broadcast, gathers, self-check) with a world of ONE rank over "
                          "the real backend: what a one-GPU box can exercise of the RCCL calls")
+    ap.add_argument("--launch-timeout", type=int, default=1500,
+                    help="self-launched multi-rank run: seconds after which ranks that have not finished are killed and a JSON "
+                         "error line is printed")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="multi-rank dry run on ONE GPU: gloo instead of RCCL, every rank computes on cuda:0 "
                          "(exercises launch/broadcast/shard/timing code where only one GPU is available)")

@@ -80,3 +80,19 @@ def test_plain_start_of_a_two_rank_rehearsal_runs_end_to_end():
     assert d["multi_gpu"]["params_identical_on_all_ranks"] is True
     assert d["multi_gpu"]["first_2048_classes_of_every_rank_equal_oracle"] == [True, True]
     assert d["multi_gpu"]["collectives_on_the_data_path"] == 0
+
+
+def test_ranks_that_never_finish_are_killed_and_reported(monkeypatch, capsys):
+    """a rendezvous that hangs: after --launch-timeout the launcher kills exactly the processes it started and prints
+    the JSON error line"""
+    import time
+    b = _bench_module()
+    monkeypatch.setattr(b, "visible_gpus", lambda: 2)
+    monkeypatch.setattr(b, "rank_commands", lambda n, argv, port, python=None, script=None:
+                        [([sys.executable, "-c", "import time; time.sleep(120)"], {}) for _ in range(n)])
+    a = b.parse_args(["--gpus", "2", "--launch-timeout", "2"])
+    t0 = time.time()
+    rc = b.self_launch(a, ["--gpus", "2"])
+    assert rc == 124 and time.time() - t0 < 30
+    out = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")]
+    assert len(out) == 1 and "did not finish" in json.loads(out[0])["error"]
