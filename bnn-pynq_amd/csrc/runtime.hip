@@ -730,7 +730,8 @@ int warm_up() {
   const int big = 8192;
   const size_t isz = (size_t)r.spec.image_bytes();
   if (reserve(big) || reserve_host(big, (size_t)big)) return -1;
-  if (!std::getenv("BNN_MI355X_NO_FEEDER") && feeder().init()) return fail("pinned staging ring: allocation failed");
+  // (the pinned ring and the reader threads of the file path are NOT created here: 48 MB of pinned memory and six threads
+  // per loaded network would be a poor default for users who never classify a large file; the first such call pays ~10 ms)
   HIP_OK(hipMemsetAsync(r.d_images[0], 0, (size_t)big * isz, r.stream));
   for (int n : {1, 2, 300, 600, 1100, 2500, 5000, big})  // one batch size inside every band of the dispatch policy
     if (enqueue(r.d_images[0], n, 10, r.d_classes, r.spec.is_cnv ? r.d_scores : nullptr, r.d_words, r.stream)) return -1;
