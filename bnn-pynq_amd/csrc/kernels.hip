@@ -656,6 +656,13 @@ __device__ __forceinline__ uint32_t chain_temp() {
   asm("" : "=v"(t));  // any value: every statement overwrites it before reading it
   return t;
 }
+// The neuron loops that step by one: the compiler otherwise counts them in a VGPR (v_add_co + a vcc branch), one
+// more VALU slot per neuron next to the pairs.  Pinning the counter to an SGPR once per iteration emits nothing.
+#ifdef BNN_VGPR_COUNTER  // A/B build only
+#define SCALAR_COUNTER(c) do { } while (0)
+#else
+#define SCALAR_COUNTER(c) asm volatile("" : "+s"(c))
+#endif
 __device__ __forceinline__ void xpop(int &acc, uint32_t w, uint32_t a, uint32_t &t) {
   asm("v_xor_b32 %0, %2, %3\n\tv_bcnt_u32_b32 %1, %0, %1" : "+v"(t), "+v"(acc) : "s"(w), "v"(a));
 }
@@ -707,6 +714,7 @@ __global__ __launch_bounds__(kBlock) void k_quad_x(const uint64_t *__restrict__ 
     uint32_t b[4] = {0, 0, 0, 0};
     for (int c = NPB - 1; c >= 0; c--) {
       kptr32 r = w + c * ROW_DW;
+      SCALAR_COUNTER(c);
       const int nt = -(int)r[0];  // (scalar) every chain starts at -t: it ends on m - t, whose sign is the decision
       int m[2][2];
   #pragma unroll
@@ -951,6 +959,7 @@ __global__ __launch_bounds__(kBlock) void k_quad(const uint64_t *__restrict__ in
     uint32_t b0[4] = {0, 0, 0, 0}, b1[4] = {0, 0, 0, 0};
     for (int c = NPB - 1; c >= 0; c--) {
       kptr32 r = w + c * ROW_DW;
+      SCALAR_COUNTER(c);
       const int t0 = (int)r[0], t1 = (int)r[1];
       // (the zeros are never materialised: the first statement of each chain writes its accumulator)
       int m[2][2] = {{0, 0}, {0, 0}}, z[2][2] = {{0, 0}, {0, 0}};
