@@ -456,6 +456,7 @@ struct Feeder {
                                  // (profiles/r03_h2d_probe.txt); behind the readers 2-4 MB pieces gave the shortest calls
   struct Piece { int chunk; size_t off_in_chunk, src_off, bytes; bool last_of_chunk; };
   uint8_t *ring = nullptr;  // kSlots x kSlotBytes, pinned
+  bool ready = false;       // init() went through: ring, events, streams and workers exist
   hipEvent_t sent[kSlots] = {};
   // Two things make the pipe faster than "pread, then one DMA queue" (tools/file_pipe_probe.cpp, profiles/r03_file_pipe_probe.txt:
   // 33-37 GB/s): the pieces alternate over TWO streams, i.e. two DMA queues (46 GB/s), and the readers write their lines
@@ -515,7 +516,8 @@ struct Feeder {
   }
   // pinned ring, events and worker threads: once per process (the threads sleep between jobs)
   int init() {
-    if (ring) return 0;
+    if (ready) return 0;
+    if (ring) return -1;  // an earlier attempt got the ring but not its events or streams: stays refused (the caller reports it)
     if (const char *e = std::getenv("BNN_MI355X_FEEDER_PIECE_MB")) {
       const int mb = std::atoi(e);
       if (mb >= 1 && mb <= 32) kSlotBytes = (size_t)mb << 20;
@@ -539,6 +541,7 @@ struct Feeder {
     if (const char *e = std::getenv("BNN_MI355X_FEEDER_THREADS")) nt = std::atoi(e);
     nt = nt < 1 ? 1 : (nt > 14 ? 14 : nt);
     for (int i = 0; i < nt; i++) workers.emplace_back([this] { worker(); });
+    ready = true;
     return 0;
   }
   void begin(const std::vector<Piece> &pcs, const uint8_t *m, int f) {
@@ -925,9 +928,10 @@ int infer_file(const ImageFile &f, int n, int ncls, int32_t *classes, int16_t *s
                    r.d_words + base, r.stream, r.time_events[2 * c], r.time_events[2 * c + 1]);
   };
   // large file: worker threads pread() it into the pinned ring piece by piece (feed_chunks); small: one or a few chunks
-  // through a pageable host chunk (stream_file)
-  const int rc = (nchunks > 1 && use_feeder((size_t)n * f.rec)) ? feed_chunks(nullptr, f.fd, f.first, f.rec, f.skip, plan, stages)
-                                                              : stream_file(f, n, true, [&](int, int slot) { return r.d_images[slot]; }, stages);
+  // through a pageable host chunk (stream_file) -- also where the ring cannot be had (no pinned memory to spare): slower, same result
+  const bool ring = nchunks > 1 && use_feeder((size_t)n * f.rec) && feeder().init() == 0;
+  const int rc = ring ? feed_chunks(nullptr, f.fd, f.first, f.rec, f.skip, plan, stages)
+                      : stream_file(f, n, true, [&](int, int slot) { return r.d_images[slot]; }, stages);
   if (rc) return -1;
   if (classes) HIP_OK(hipMemcpyAsync(classes, r.d_classes, (size_t)n * 4, hipMemcpyDeviceToHost, r.stream));
   if (want_scores) HIP_OK(hipMemcpyAsync(scores, r.d_scores, (size_t)n * 128, hipMemcpyDeviceToHost, r.stream));
