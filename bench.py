@@ -409,10 +409,12 @@ def main():
         stats = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(stats, mine)
         samp_i, samp_c = imgs[:k].to(cdev).contiguous(), classes[:k].to(cdev).contiguous()
-        gi = [torch.zeros_like(samp_i) for _ in range(world)] if rank == 0 else None
-        gc = [torch.zeros_like(samp_c) for _ in range(world)] if rank == 0 else None
-        dist.gather(samp_i, gi, dst=0)
-        dist.gather(samp_c, gc, dst=0)
+        # (all_gather, RCCL's native collective, rather than gather, which the NCCL backend emulates with grouped send/recv:
+        # 6 MB per rank, after the timed region)
+        gi = [torch.zeros_like(samp_i) for _ in range(world)]
+        gc = [torch.zeros_like(samp_c) for _ in range(world)]
+        dist.all_gather(gi, samp_i)
+        dist.all_gather(gc, samp_c)
         if rank == 0:
             crcs = ["%08x" % int(x[2].item()) for x in stats]
             multi = {"ranks": world, "backend": "gloo (rehearsal: every rank on cuda:0)" if a.rehearse_gloo else "nccl (RCCL)",
