@@ -23,6 +23,7 @@
 #include <sched.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
@@ -34,6 +35,7 @@
 #include <memory>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/bnn_mi355x.h"
@@ -144,6 +146,11 @@ struct Runtime {
   // workspace
   int cap = 0;
   void *buf0 = nullptr, *buf1 = nullptr;
+  // second compute lane of the host paths ("Two compute lanes" below): its own workspace and stream
+  int cap2 = 0;
+  void *buf0b = nullptr, *buf1b = nullptr;
+  hipStream_t stream2 = nullptr;
+  hipEvent_t lane2_done = nullptr;
   // host-buffer path: two image staging buffers in HBM (ping-pong) + results for the whole call
   int stage_cap = 0;
   uint8_t *d_images[2] = {nullptr, nullptr};
@@ -207,6 +214,8 @@ int bind_device() {
   if (!r.stream) {
     HIP_OK(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&r.copy_stream, hipStreamNonBlocking));
+    HIP_OK(hipStreamCreateWithFlags(&r.stream2, hipStreamNonBlocking));
+    HIP_OK(hipEventCreateWithFlags(&r.lane2_done, hipEventDisableTiming));
     for (int i = 0; i < 2; i++) {
       HIP_OK(hipEventCreateWithFlags(&r.copied[i], hipEventDisableTiming));
       HIP_OK(hipEventCreateWithFlags(&r.consumed[i], hipEventDisableTiming));
@@ -226,6 +235,7 @@ struct DrainOnFailure {
     if (!armed) return;
     Runtime &r = rt();
     if (r.stream) (void)hipStreamSynchronize(r.stream);
+    if (r.stream2) (void)hipStreamSynchronize(r.stream2);
     if (r.copy_stream) (void)hipStreamSynchronize(r.copy_stream);
   }
 };
@@ -262,7 +272,7 @@ int upload_blob() {
 
 void free_workspace() {
   Runtime &r = rt();
-  if (r.cap == 0 && r.stage_cap == 0 && r.res_cap == 0 && !r.d_pp_src && !r.d_pp_rec && !r.file_cap && !r.all_cap && !r.d_rec_cap) return;
+  if (r.cap == 0 && r.cap2 == 0 && r.stage_cap == 0 && r.res_cap == 0 && !r.d_pp_src && !r.d_pp_rec && !r.file_cap && !r.all_cap && !r.d_rec_cap) return;
   if (r.device >= 0) (void)hipSetDevice(r.device);
   (void)hipDeviceSynchronize();
   (void)hipFree(r.buf0); (void)hipFree(r.buf1); (void)hipFree(r.d_images[0]); (void)hipFree(r.d_images[1]);
@@ -271,6 +281,9 @@ void free_workspace() {
   r.d_scores = nullptr; r.d_classes = nullptr; r.d_words = nullptr;
   r.cap = r.stage_cap = 0;
   r.res_cap = 0;
+  (void)hipFree(r.buf0b); (void)hipFree(r.buf1b);
+  r.buf0b = r.buf1b = nullptr;
+  r.cap2 = 0;
   (void)hipFree(r.d_all);
   r.d_all = nullptr;
   r.all_cap = 0;
@@ -320,6 +333,72 @@ int reserve(int n) {
   return 0;
 }
 
+// Two compute lanes.  A host-path call cuts its batch into chunks so that copies and kernels overlap (plan_chunks); on ONE
+// stream the nine launches of every chunk follow each other with the dispatcher's gap between them and each with its
+// own tail, and the small chunks at the head of the plan pay that at 2 048-8 192 images a time: the plan of 131 072
+// CIFAR images takes 11.12 ms of kernels against 10.40 ms for the batch in one pass.  With the chunks alternating over
+// two streams -- a second activation workspace, the staging buffer of slot s feeds lane s -- one lane's gaps and tails
+// are filled by the other's kernels: 10.61 ms (tools/two_lane_probe.py, profiles/r03_two_lane_probe.txt).
+// Only where the chunks arrive through the pinned ring, i.e. by DMA: with the runtime's pageable copies (host buffers,
+// small files) two lanes are SLOWER -- 1 048 576 images from a host buffer 87.7 -> 100.7 ms, 262 144 22.4 -> 24.5, three
+// alternating runs each -- while the ring-fed file path gains 4 % (92.1 -> 88.5 ms; profiles/r03_two_lanes_ab.txt).
+// BNN_MI355X_LANES=1 / =2 force one / two lanes (A/B); stage profiling and the stage-output hook always run on one lane.
+int lanes_for(int nchunks, bool through_ring) {
+  static const int forced = [] { const char *e = std::getenv("BNN_MI355X_LANES"); return e ? std::atoi(e) : 0; }();
+  const Runtime &r = rt();
+  if (nchunks < 3 || r.profiling || r.debug_last_stage >= 0 || forced == 1) return 1;
+  return (through_ring || forced == 2) ? 2 : 1;
+}
+// the second lane's activation workspace for `n` images per pass
+int reserve2(int n) {
+  Runtime &r = rt();
+  if (n > kMaxChunk) n = kMaxChunk;
+  if (n <= r.cap2) return 0;
+  if (bind_device()) return -1;
+  HIP_OK(hipDeviceSynchronize());
+  (void)hipFree(r.buf0b); (void)hipFree(r.buf1b);
+  r.buf0b = r.buf1b = nullptr;
+  r.cap2 = 0;
+  size_t b0, b1;
+  if (r.spec.is_cnv) cnv_workspace_bytes(r.spec.abits, &b0, &b1);
+  else lfc_workspace_bytes(r.spec.abits, &b0, &b1);
+  HIP_OK(hipMalloc(&r.buf0b, (size_t)n * b0 + 256));
+  HIP_OK(hipMalloc(&r.buf1b, (size_t)n * b1 + 256));
+  r.cap2 = n;
+  return 0;
+}
+// chunk c of a call that runs on `lanes` lanes: its stream
+hipStream_t lane_stream(int c, int lanes) { return (lanes == 2 && (c & 1)) ? rt().stream2 : rt().stream; }
+// all chunks are enqueued: whatever follows on r.stream (the results' way back) comes behind the second lane too
+int join_lanes(int lanes) {
+  Runtime &r = rt();
+  if (lanes == 2) {
+    HIP_OK(hipEventRecord(r.lane2_done, r.stream2));
+    HIP_OK(hipStreamWaitEvent(r.stream, r.lane2_done, 0));
+  }
+  return 0;
+}
+// device time of a call's chunks, ms: the union of their [t0, t1] intervals (on one lane they do not overlap: the sum)
+int chunks_device_ms(int nchunks, double *out) {
+  Runtime &r = rt();
+  std::vector<std::pair<float, float>> iv((size_t)nchunks);
+  for (int c = 0; c < nchunks; c++) {
+    float a = 0.f, d = 0.f;
+    if (c) HIP_OK(hipEventElapsedTime(&a, r.time_events[0], r.time_events[2 * c]));
+    HIP_OK(hipEventElapsedTime(&d, r.time_events[2 * c], r.time_events[2 * c + 1]));
+    iv[(size_t)c] = {a, a + d};
+  }
+  std::sort(iv.begin(), iv.end());
+  double total = 0.0;
+  float lo = iv[0].first, hi = iv[0].second;
+  for (int c = 1; c < nchunks; c++) {
+    if (iv[(size_t)c].first > hi) { total += hi - lo; lo = iv[(size_t)c].first; hi = iv[(size_t)c].second; }
+    else if (iv[(size_t)c].second > hi) hi = iv[(size_t)c].second;
+  }
+  *out = total + (hi - lo);
+  return 0;
+}
+
 // host-buffer path: staging for `chunk` images x 2 and result buffers for `n_total` images
 int reserve_host(int chunk, size_t n_total) {
   Runtime &r = rt();
@@ -352,11 +431,13 @@ int reserve_host(int chunk, size_t n_total) {
 // enqueue one chunk (n <= cap) whose images are already in HBM
 // t0 / t1 (optional): this chunk's device time is t0 -> t1 (kernels.h)
 int enqueue(const uint8_t *d_imgs, int n, int ncls, int32_t *d_classes, int16_t *d_scores, uint64_t *d_words,
-            hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr) {
+            hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr, int lane = 0) {
   Runtime &r = rt();
   hipError_t e;
   hipEvent_t *evs = nullptr;
-  if (r.ws_pending && r.ws_last != s) {  // an earlier device-pointer call on another stream may still own the workspace
+  void *const ws0 = lane ? r.buf0b : r.buf0, *const ws1 = lane ? r.buf1b : r.buf1;
+  // (the second lane's workspace is used by host-path calls only, and those drain their streams before they return)
+  if (lane == 0 && r.ws_pending && r.ws_last != s) {  // an earlier device-pointer call on another stream may still own the workspace
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
     // A capturing stream must not wait on an event recorded outside its capture (the capture would be invalidated, or
@@ -387,7 +468,7 @@ int enqueue(const uint8_t *d_imgs, int n, int ncls, int32_t *d_classes, int16_t 
   }
   if (r.spec.is_cnv) {
     CnvLaunch a{};
-    a.images = d_imgs; a.n = n; a.buf0 = r.buf0; a.buf1 = r.buf1;
+    a.images = d_imgs; a.n = n; a.buf0 = ws0; a.buf1 = ws1;
     for (int l = 0; l < 9; l++) a.rows[l] = r.rows[l];
     a.l0_mfma = r.l0_mfma;
     a.l1_mfma = r.l1_mfma ? r.d_l1_mfma : nullptr;
@@ -399,7 +480,7 @@ int enqueue(const uint8_t *d_imgs, int n, int ncls, int32_t *d_classes, int16_t 
     e = run_cnv(r.spec.id, a);
   } else {
     LfcLaunch a{};
-    a.images = d_imgs; a.n = n; a.buf0 = r.buf0; a.buf1 = r.buf1;
+    a.images = d_imgs; a.n = n; a.buf0 = ws0; a.buf1 = ws1;
     for (int l = 0; l < 4; l++) a.rows[l] = r.rows[l];
     a.words = d_words;
     a.classes = d_classes; a.number_class = ncls; a.stream = s; a.events = evs;
@@ -576,10 +657,10 @@ bool use_feeder(size_t bytes) {
 }
 
 // n images from host memory (fd < 0) or from an open file, cut by `plan`, through the pinned ring into the two HBM
-// chunk buffers; consume(c, base, m, slot) enqueues chunk c's stages on r.stream once its bytes (label bytes
-// stripped: rec > isz) are in r.d_images[slot] and r.stream has been made to wait for them.
+// chunk buffers; consume(c, base, m, slot) enqueues chunk c's stages on its lane's stream (lane_stream) once its bytes
+// (label bytes stripped: rec > isz) are in r.d_images[slot] and that stream has been made to wait for them.
 template <typename Consume>
-int feed_chunks(const uint8_t *mem, int fd, size_t first, size_t rec, size_t skip, const std::vector<int> &plan, Consume consume) {
+int feed_chunks(const uint8_t *mem, int fd, size_t first, size_t rec, size_t skip, const std::vector<int> &plan, int lanes, Consume consume) {
   Runtime &r = rt();
   Feeder &F = feeder();
   if (F.init()) return fail("pinned staging ring: allocation failed");
@@ -652,9 +733,9 @@ int feed_chunks(const uint8_t *mem, int fd, size_t first, size_t rec, size_t ski
       if (e != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(e));
     }
     HIP_OK(hipEventRecord(r.copied[slot], r.copy_stream));
-    HIP_OK(hipStreamWaitEvent(r.stream, r.copied[slot], 0));
+    HIP_OK(hipStreamWaitEvent(lane_stream(c, lanes), r.copied[slot], 0));
     if (consume(c, base, m, slot)) return -1;
-    HIP_OK(hipEventRecord(r.consumed[slot], r.stream));
+    HIP_OK(hipEventRecord(r.consumed[slot], lane_stream(c, lanes)));
   }
   return 0;
 }
@@ -673,7 +754,13 @@ int infer_host(const uint8_t *imgs, int n, int ncls, int32_t *classes, int16_t *
   const std::vector<int> plan = plan_chunks(n, r.debug_last_stage >= 0, false);
   const int chunk = largest_chunk(plan);
   const int nchunks = (int)plan.size() - 1;
-  if (reserve(chunk) || reserve_host(chunk, (size_t)n)) return -1;
+  // The pinned ring is for FILES.  A buffer in host memory goes faster without it: the runtime's own pageable path moves
+  // a 100 MB chunk at 54 GB/s (profiles/r03_h2d_probe.txt), the ring's 4-8 MB pieces reach 49-52 and add a copy
+  // (measured, same box: 13.8 ms through the ring, 12.7 ms without, 131 072 CIFAR images).  BNN_MI355X_FEED_HOST=1 forces it.
+  static const bool feed_host = std::getenv("BNN_MI355X_FEED_HOST") != nullptr;
+  const bool fed = feed_host && nchunks > 1 && use_feeder((size_t)n * isz);
+  const int lanes = lanes_for(nchunks, fed);
+  if (reserve(chunk) || (lanes == 2 && reserve2(chunk)) || reserve_host(chunk, (size_t)n)) return -1;
   while ((int)r.time_events.size() < 2 * nchunks) {
     hipEvent_t e;
     HIP_OK(hipEventCreateWithFlags(&e, kTimeEventFlags));
@@ -686,14 +773,9 @@ int infer_host(const uint8_t *imgs, int n, int ncls, int32_t *classes, int16_t *
   // would otherwise make the host wait for each chunk's kernels before it can queue the next copy).
   auto stages = [&](int c, int base, int m, int slot) {
     return enqueue(r.d_images[slot], m, ncls, classes ? r.d_classes + base : nullptr, want_scores ? r.d_scores + (size_t)base * 64 : nullptr,
-                   r.d_words + base, r.stream, r.time_events[2 * c], r.time_events[2 * c + 1]);
+                   r.d_words + base, lane_stream(c, lanes), r.time_events[2 * c], r.time_events[2 * c + 1], lanes == 2 ? (c & 1) : 0);
   };
-  // The pinned ring is for FILES.  A buffer in host memory goes faster without it: the runtime's own pageable path moves
-  // a 100 MB chunk at 54 GB/s (profiles/r03_h2d_probe.txt), the ring's 4-8 MB pieces reach 49-52 and add a copy
-  // (measured, same box: 13.8 ms through the ring, 12.7 ms without, 131 072 CIFAR images).  BNN_MI355X_FEED_HOST=1 forces it.
-  static const bool feed_host = std::getenv("BNN_MI355X_FEED_HOST") != nullptr;
-  const bool fed = feed_host && nchunks > 1 && use_feeder((size_t)n * isz);
-  if (fed && feed_chunks(imgs, -1, 0, isz, 0, plan, stages)) return -1;
+  if (fed && feed_chunks(imgs, -1, 0, isz, 0, plan, lanes, stages)) return -1;
   for (int c = 0; c < (fed ? 0 : nchunks); c++) {
     const int base = plan[c], m = plan[c + 1] - plan[c], slot = c & 1;
     if (nchunks == 1) {  // nothing to overlap: stay on one stream (fewer driver round trips for small calls)
@@ -702,21 +784,18 @@ int infer_host(const uint8_t *imgs, int n, int ncls, int32_t *classes, int16_t *
       if (c >= 2) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));
       HIP_OK(hipMemcpyAsync(r.d_images[slot], imgs + (size_t)base * isz, (size_t)m * isz, hipMemcpyHostToDevice, r.copy_stream));
       HIP_OK(hipEventRecord(r.copied[slot], r.copy_stream));
-      HIP_OK(hipStreamWaitEvent(r.stream, r.copied[slot], 0));
+      HIP_OK(hipStreamWaitEvent(lane_stream(c, lanes), r.copied[slot], 0));
     }
     if (stages(c, base, m, slot)) return -1;
-    if (nchunks > 1) HIP_OK(hipEventRecord(r.consumed[slot], r.stream));
+    if (nchunks > 1) HIP_OK(hipEventRecord(r.consumed[slot], lane_stream(c, lanes)));
   }
+  if (join_lanes(lanes)) return -1;
   if (classes) HIP_OK(hipMemcpyAsync(classes, r.d_classes, (size_t)n * 4, hipMemcpyDeviceToHost, r.stream));
   if (want_scores) HIP_OK(hipMemcpyAsync(scores, r.d_scores, (size_t)n * 128, hipMemcpyDeviceToHost, r.stream));
   if (words && !r.spec.is_cnv) HIP_OK(hipMemcpyAsync(words, r.d_words, (size_t)n * 8, hipMemcpyDeviceToHost, r.stream));
   HIP_OK(hipStreamSynchronize(r.stream));
   double total_ms = 0.0;
-  for (int c = 0; c < nchunks; c++) {
-    float ms = 0.f;
-    HIP_OK(hipEventElapsedTime(&ms, r.time_events[2 * c], r.time_events[2 * c + 1]));
-    total_ms += ms;
-  }
+  if (chunks_device_ms(nchunks, &total_ms)) return -1;
   if (usec) *usec = (float)(total_ms * 1000.0 / n);
   drain.ok();
   return 0;
@@ -837,10 +916,10 @@ struct ChunkReader {
 // Streams images [0, n) of an open file into HBM, chunk by chunk (plan_chunks; reader
 // threads one chunk ahead of the copy).  Chunk c lands packed (labels stripped) at dst(base, slot) and
 // `consume(c, base, m, slot)` is called once its copy and strip are enqueued on copy_stream and
-// r.stream has been made to wait for them.  reuse_slots: the destinations alternate between two
+// the chunk's lane (lane_stream(c, lanes)) has been made to wait for them.  reuse_slots: the destinations alternate between two
 // buffers, so a chunk's copy must wait until the stages of the chunk two before have consumed it.
 template <typename Dst, typename Consume>
-int stream_file(const ImageFile &f, int n, bool reuse_slots, Dst dst, Consume consume) {
+int stream_file(const ImageFile &f, int n, bool reuse_slots, int lanes, Dst dst, Consume consume) {
   Runtime &r = rt();
   const std::vector<int> plan = plan_chunks(n, false, true);
   const int chunk = largest_chunk(plan);
@@ -895,11 +974,11 @@ int stream_file(const ImageFile &f, int n, bool reuse_slots, Dst dst, Consume co
     }
     if (cs != r.stream) {
       HIP_OK(hipEventRecord(r.copied[slot], cs));
-      HIP_OK(hipStreamWaitEvent(r.stream, r.copied[slot], 0));
+      HIP_OK(hipStreamWaitEvent(lane_stream(c, lanes), r.copied[slot], 0));
     }
     if (consume(c, base, m, slot)) return -1;
     // (with reuse_slots the consumer's stages read `packed`; without, only the strip kernel reads d_file[slot])
-    if (nchunks > 1) HIP_OK(hipEventRecord(r.consumed[slot], reuse_slots ? r.stream : r.copy_stream));
+    if (nchunks > 1) HIP_OK(hipEventRecord(r.consumed[slot], reuse_slots ? lane_stream(c, lanes) : r.copy_stream));
   }
   return 0;
 }
@@ -915,7 +994,11 @@ int infer_file(const ImageFile &f, int n, int ncls, int32_t *classes, int16_t *s
   const std::vector<int> plan = plan_chunks(n, false, true);  // (stream_file walks the same plan)
   const int chunk = largest_chunk(plan);
   const int nchunks = (int)plan.size() - 1;
-  if (reserve(chunk) || reserve_host(chunk, (size_t)n)) return -1;
+  // large file: worker threads pread() it into the pinned ring piece by piece (feed_chunks); small: one or a few chunks
+  // through a pageable host chunk (stream_file) -- also where the ring cannot be had (no pinned memory to spare): slower, same result
+  const bool ring = nchunks > 1 && use_feeder((size_t)n * f.rec) && feeder().init() == 0;
+  const int lanes = lanes_for(nchunks, ring);
+  if (reserve(chunk) || (lanes == 2 && reserve2(chunk)) || reserve_host(chunk, (size_t)n)) return -1;
   while ((int)r.time_events.size() < 2 * nchunks) {
     hipEvent_t e;
     HIP_OK(hipEventCreateWithFlags(&e, kTimeEventFlags));
@@ -925,25 +1008,18 @@ int infer_file(const ImageFile &f, int n, int ncls, int32_t *classes, int16_t *s
   const bool want_scores = scores && r.spec.is_cnv;
   auto stages = [&](int c, int base, int m, int slot) {
     return enqueue(r.d_images[slot], m, ncls, classes ? r.d_classes + base : nullptr, want_scores ? r.d_scores + (size_t)base * 64 : nullptr,
-                   r.d_words + base, r.stream, r.time_events[2 * c], r.time_events[2 * c + 1]);
+                   r.d_words + base, lane_stream(c, lanes), r.time_events[2 * c], r.time_events[2 * c + 1], lanes == 2 ? (c & 1) : 0);
   };
-  // large file: worker threads pread() it into the pinned ring piece by piece (feed_chunks); small: one or a few chunks
-  // through a pageable host chunk (stream_file) -- also where the ring cannot be had (no pinned memory to spare): slower, same result
-  const bool ring = nchunks > 1 && use_feeder((size_t)n * f.rec) && feeder().init() == 0;
-  const int rc = ring ? feed_chunks(nullptr, f.fd, f.first, f.rec, f.skip, plan, stages)
-                      : stream_file(f, n, true, [&](int, int slot) { return r.d_images[slot]; }, stages);
-  if (rc) return -1;
+  const int rc = ring ? feed_chunks(nullptr, f.fd, f.first, f.rec, f.skip, plan, lanes, stages)
+                      : stream_file(f, n, true, lanes, [&](int, int slot) { return r.d_images[slot]; }, stages);
+  if (rc || join_lanes(lanes)) return -1;
   if (classes) HIP_OK(hipMemcpyAsync(classes, r.d_classes, (size_t)n * 4, hipMemcpyDeviceToHost, r.stream));
   if (want_scores) HIP_OK(hipMemcpyAsync(scores, r.d_scores, (size_t)n * 128, hipMemcpyDeviceToHost, r.stream));
   if (words && !r.spec.is_cnv) HIP_OK(hipMemcpyAsync(words, r.d_words, (size_t)n * 8, hipMemcpyDeviceToHost, r.stream));
   HIP_OK(hipStreamSynchronize(r.stream));
   HIP_OK(hipStreamSynchronize(r.copy_stream));
   double total_ms = 0.0;
-  for (int c = 0; c < nchunks; c++) {
-    float ms = 0.f;
-    HIP_OK(hipEventElapsedTime(&ms, r.time_events[2 * c], r.time_events[2 * c + 1]));
-    total_ms += ms;
-  }
+  if (chunks_device_ms(nchunks, &total_ms)) return -1;
   if (usec) *usec = (float)(total_ms * 1000.0 / n);
   drain.ok();
   return 0;
@@ -956,7 +1032,7 @@ int load_file_resident(const ImageFile &f, int n) {
   if (bind_device() || grow(r.d_all, r.all_cap, (size_t)n * isz + 256)) return -1;
   DrainOnFailure drain;
   if (stream_file(
-          f, n, false, [&](int base, int) { return r.d_all + (size_t)base * isz; }, [&](int, int, int, int) { return 0; }))
+          f, n, false, 1, [&](int base, int) { return r.d_all + (size_t)base * isz; }, [&](int, int, int, int) { return 0; }))
     return -1;
   HIP_OK(hipStreamSynchronize(r.copy_stream));
   drain.ok();

@@ -741,3 +741,52 @@ def test_file_abi_either_side_of_the_pinned_ring_threshold(n, tmp_path):
         got = np.ctypeslib.as_array(p, (n,)).copy()
         net.L.free_results(p)
         assert (got == want).all()
+
+
+def test_host_paths_on_two_compute_lanes(tmp_path):
+    """a ring-fed file call of three or more chunks alternates them over two streams and two activation workspaces
+    (runtime.hip, "Two compute lanes"): classes of every image against the restatement -- CNV (label bytes stripped on
+    the device) and LFC, ragged last chunk, repeated calls (the lanes' buffers are reused) --, `usecPerImage` the union of
+    the chunks' device intervals (positive, below the wall time); host buffers take one lane by default: both forced
+    settings (BNN_MI355X_LANES=1 / =2) give the restatement's raw scores for buffers and files"""
+    import subprocess
+    import sys
+    import time
+    for network, dataset, n in (("cnvW1A1", "cifar10", 23001), ("cnvW2A2", "cifar10", 20011), ("lfcW1A1", "mnist", 70003)):
+        net, o = gpu_net(network, dataset), oracle(network, dataset)
+        k = C.c_int(0)
+        bases = (C.c_int * 64)()
+        assert net.L.bnn_mi355x_chunk_plan(n, 1, bases, 64) >= 4         # three or more chunks, > 24 MB: ring-fed, two lanes
+        imgs = rand_images(network, n, 77)
+        want = o.classes_batched(imgs, 10)
+        path = str(tmp_path / (network + ".bin"))
+        with open(path, "wb") as f:
+            if net.is_cnv:
+                r = np.empty((n, 3073), np.uint8); r[:, 0] = 3; r[:, 1:] = imgs; f.write(r.tobytes())
+            else:
+                f.write((0x803).to_bytes(4, "big") + n.to_bytes(4, "big") + (28).to_bytes(4, "big") * 2 + imgs.tobytes())
+        for rep in range(3):
+            usec = C.c_float(0)
+            t0 = time.perf_counter()
+            p = net.L.inference_multiple(path.encode(), 10, C.byref(k), C.byref(usec), 0)
+            wall_us = (time.perf_counter() - t0) * 1e6
+            assert p and k.value == n
+            got = np.ctypeslib.as_array(p, (n,)).copy()
+            net.L.free_results(p)
+            assert (got == want).all(), (network, "file", rep)
+            assert 0 < usec.value * n < wall_us, (network, usec.value * n, wall_us)
+        got = net.raw(imgs)                                               # host buffer (one lane by default)
+        assert (got == (o.scores_fast(imgs) if net.is_cnv else o.words_fast(imgs))).all(), network
+    code = (
+        "import sys, ctypes as C, numpy as np; sys.path[:0] = [%r, %r]\n"
+        "import gpu_lib as gl, oracle_lib as ol\n"
+        "net = gl.Net('cnvW1A1', 'cifar10'); o = ol.Oracle('cnvW1A1', ol.param_dir('cifar10', 'cnvW1A1'))\n"
+        "imgs = np.random.default_rng(5).integers(0, 256, (23001, 3072), dtype=np.uint8)\n"
+        "for rep in range(2): assert (net.raw(imgs) == o.scores_fast(imgs)).all()\n"
+        "r = np.empty((23001, 3073), np.uint8); r[:, 0] = 1; r[:, 1:] = imgs; open(%r, 'wb').write(r.tobytes())\n"
+        "k = C.c_int(0); p = net.L.inference_multiple(%r, 10, C.byref(k), None, 0)\n"
+        "assert p and (np.ctypeslib.as_array(p, (23001,)) == o.classes_batched(imgs, 10)).all()\n"
+        "print('lanes-ok')\n" % (os.path.join(gl.ROOT, "tests"), os.path.join(gl.ROOT, "bnn-pynq_amd"), str(tmp_path / "f.bin"), str(tmp_path / "f.bin").encode()))
+    for lanes in ("1", "2"):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BNN_MI355X_LANES=lanes), capture_output=True, text=True, timeout=600)
+        assert "lanes-ok" in out.stdout, lanes + out.stdout[-1500:] + out.stderr[-3000:]
