@@ -57,11 +57,13 @@ namespace bnn {
 namespace {
 
 constexpr int kMaxChunk = 131072;  // images per pass through the stages
+constexpr int kStageSlots = 4;      // HBM staging buffers of the host paths: two on one compute lane, four on two
 // Events that only TIME device work: a device-scope release at the record point instead of a flush to system scope
 // ("useful to obtain more precise timings of commands between events", hip_runtime_api.h).  Nothing on the host reads
 // results on the strength of these events: every entry point fetches them with a copy + stream synchronisation.
 constexpr unsigned kTimeEventFlags = hipEventReleaseToDevice;
-constexpr int kHostChunk = 32768;  // host-buffer / file path: H2D of chunk i+1 overlaps the stages of chunk i (largest chunk)
+constexpr int kHostChunk = 32768;  // host-buffer / file path: H2D of chunk i+1 overlaps the stages of chunk i (largest chunk; LFC nets)
+constexpr int kHostChunkCnv = 16384;  // ... the CNV nets since the chunks run on two compute lanes (below)
 constexpr int kHeadChunk = 2048;   // ... the first chunk: what the stages wait for before anything runs
 
 // Chunk boundaries of a host-buffer / file call: base[c] .. base[c+1] are the images of chunk c.
@@ -73,12 +75,15 @@ constexpr int kHeadChunk = 2048;   // ... the first chunk: what the stages wait 
 // pinned ring and two DMA queues at ~46 GB/s = 15 M/s, against 12.5 M/s of stages), so a call is compute-bound: what ends
 // it is the last chunk's stages whatever their size -- no ramp down -- and small chunks cost stage efficiency (2 048 images
 // run at 9.7 M/s, 32 768 at 12.1): x1.5 per step from 2 048 (buffer) / 4 096 (file) images up to 32 768
-// (profiles/r03_chunk_plan_sweep.txt, r03_file_path_two_queues_plan_sweep.txt).
+// (profiles/r03_chunk_plan_sweep.txt, r03_file_path_two_queues_plan_sweep.txt).  Since the chunks alternate over two
+// compute lanes ("Two compute lanes" below) one chunk's launch gaps and tails are filled by the other's kernels, small
+// chunks cost less and the CNV plan stops growing at 16 384: 131 072 images from a buffer 11.36 -> 11.02 ms, 1 048 576
+// 87.2 -> 84.5 ms, from a file 88.4 -> 86.3 ms (profiles/r03_two_lanes_plan_sweep.txt).
 // BNN_MI355X_CHUNKS=head:tail:max[:growth%] overrides the sizes (0 = no ramp at that end; tuning / A-B runs).
 std::vector<int> plan_chunks(int n, bool single, bool from_file) {
   // (sizes are tuned in bytes on CIFAR records: an MNIST image is a quarter of one)
   const int scale = net_spec(BNN_NETWORK).is_cnv ? 1 : 4;
-  int head = (from_file ? 2 : 1) * kHeadChunk * scale, tail = 0, big = kHostChunk, growth = 150;
+  int head = (from_file ? 2 : 1) * kHeadChunk * scale, tail = 0, big = net_spec(BNN_NETWORK).is_cnv ? kHostChunkCnv : kHostChunk, growth = 150;
   if (const char *e = std::getenv("BNN_MI355X_CHUNKS")) {
     int h = 0, t = 0, b = 0, g = growth;
     const int got = std::sscanf(e, "%d:%d:%d:%d", &h, &t, &b, &g);
@@ -109,7 +114,7 @@ std::vector<int> plan_chunks(int n, bool single, bool from_file) {
     }
   }
   // a small remainder joins the chunk in front of it (a chunk of a few hundred images costs nine launches all the same)
-  if (back.empty() && front.size() >= 2 && front.back() * 2 < front[front.size() - 2] && front.back() + front[front.size() - 2] <= kHostChunk) {
+  if (back.empty() && front.size() >= 2 && front.back() * 2 < front[front.size() - 2] && front.back() + front[front.size() - 2] <= big) {
     front[front.size() - 2] += front.back();
     front.pop_back();
   }
@@ -153,7 +158,9 @@ struct Runtime {
   hipEvent_t lane2_done = nullptr;
   // host-buffer path: two image staging buffers in HBM (ping-pong) + results for the whole call
   int stage_cap = 0;
-  uint8_t *d_images[2] = {nullptr, nullptr};
+  // (kStageSlots buffers exist once a call has run on two lanes: each lane consumes one while the next chunk of each arrives)
+  int stage_slots = 0;
+  uint8_t *d_images[kStageSlots] = {};
   size_t res_cap = 0;
   int16_t *d_scores = nullptr;
   int32_t *d_classes = nullptr;
@@ -165,14 +172,15 @@ struct Runtime {
   hipEvent_t ws_event = nullptr;
   hipStream_t ws_last = nullptr;  // the caller's stream of that call (may be the null stream: hence the flag)
   bool ws_pending = false;
-  hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
+  hipEvent_t copied[kStageSlots] = {}, consumed[kStageSlots] = {};
   std::vector<hipEvent_t> time_events;
   // file path: records as they lie on disk, two host chunks (filled by reader threads) and two HBM chunks
   size_t file_cap = 0;
   std::unique_ptr<uint8_t[]> h_file[2];
   uint8_t *d_file[2] = {nullptr, nullptr};
   size_t d_rec_cap = 0;  // feeder path: capacity of d_rec[] (records as they lie on disk, label bytes included)
-  uint8_t *d_rec[2] = {nullptr, nullptr};
+  int rec_slots = 0;
+  uint8_t *d_rec[kStageSlots] = {};
   hipEvent_t file_sent[2] = {nullptr, nullptr};
   uint8_t *d_all = nullptr;  // a whole input file's images, resident (fault campaigns)
   size_t all_cap = 0;
@@ -216,7 +224,7 @@ int bind_device() {
     HIP_OK(hipStreamCreateWithFlags(&r.copy_stream, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&r.stream2, hipStreamNonBlocking));
     HIP_OK(hipEventCreateWithFlags(&r.lane2_done, hipEventDisableTiming));
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < kStageSlots; i++) {
       HIP_OK(hipEventCreateWithFlags(&r.copied[i], hipEventDisableTiming));
       HIP_OK(hipEventCreateWithFlags(&r.consumed[i], hipEventDisableTiming));
     }
@@ -275,11 +283,12 @@ void free_workspace() {
   if (r.cap == 0 && r.cap2 == 0 && r.stage_cap == 0 && r.res_cap == 0 && !r.d_pp_src && !r.d_pp_rec && !r.file_cap && !r.all_cap && !r.d_rec_cap) return;
   if (r.device >= 0) (void)hipSetDevice(r.device);
   (void)hipDeviceSynchronize();
-  (void)hipFree(r.buf0); (void)hipFree(r.buf1); (void)hipFree(r.d_images[0]); (void)hipFree(r.d_images[1]);
+  (void)hipFree(r.buf0); (void)hipFree(r.buf1);
+  for (auto &b : r.d_images) { (void)hipFree(b); b = nullptr; }
   (void)hipFree(r.d_scores); (void)hipFree(r.d_classes); (void)hipFree(r.d_words);
-  r.buf0 = r.buf1 = nullptr; r.d_images[0] = r.d_images[1] = nullptr;
+  r.buf0 = r.buf1 = nullptr;
   r.d_scores = nullptr; r.d_classes = nullptr; r.d_words = nullptr;
-  r.cap = r.stage_cap = 0;
+  r.cap = r.stage_cap = r.stage_slots = 0;
   r.res_cap = 0;
   (void)hipFree(r.buf0b); (void)hipFree(r.buf1b);
   r.buf0b = r.buf1b = nullptr;
@@ -289,9 +298,9 @@ void free_workspace() {
   r.all_cap = 0;
   (void)hipFree(r.d_file[0]); (void)hipFree(r.d_file[1]);
   r.d_file[0] = r.d_file[1] = nullptr;
-  (void)hipFree(r.d_rec[0]); (void)hipFree(r.d_rec[1]);
-  r.d_rec[0] = r.d_rec[1] = nullptr;
+  for (auto &b : r.d_rec) { (void)hipFree(b); b = nullptr; }
   r.d_rec_cap = 0;
+  r.rec_slots = 0;
   r.h_file[0].reset(); r.h_file[1].reset();
   r.file_cap = 0;
   (void)hipFree(r.d_pp_src); (void)hipFree(r.d_pp_tmp); (void)hipFree(r.d_pp_rec); (void)hipFree(r.d_pp_coef);
@@ -339,15 +348,15 @@ int reserve(int n) {
 // CIFAR images takes 11.12 ms of kernels against 10.40 ms for the batch in one pass.  With the chunks alternating over
 // two streams -- a second activation workspace, the staging buffer of slot s feeds lane s -- one lane's gaps and tails
 // are filled by the other's kernels: 10.61 ms (tools/two_lane_probe.py, profiles/r03_two_lane_probe.txt).
-// Only where the chunks arrive through the pinned ring, i.e. by DMA: with the runtime's pageable copies (host buffers,
-// small files) two lanes are SLOWER -- 1 048 576 images from a host buffer 87.7 -> 100.7 ms, 262 144 22.4 -> 24.5, three
-// alternating runs each -- while the ring-fed file path gains 4 % (92.1 -> 88.5 ms; profiles/r03_two_lanes_ab.txt).
-// BNN_MI355X_LANES=1 / =2 force one / two lanes (A/B); stage profiling and the stage-output hook always run on one lane.
-int lanes_for(int nchunks, bool through_ring) {
-  static const int forced = [] { const char *e = std::getenv("BNN_MI355X_LANES"); return e ? std::atoi(e) : 0; }();
+// Each lane needs its own pair of staging buffers (slots_for: four in all): with two, both are held by the two chunks
+// in flight, the next copy cannot start before one of them ends, and a call from a host buffer got SLOWER (1 048 576
+// images 87.7 -> 100.7 ms); with four: 131 072 images from a host buffer 11.55 -> 11.3 ms, from a file 12.6-13.3 ->
+// 11.7-12.0 ms, 524 288 from a file 46.1-48.3 -> 44.6-44.9 ms (profiles/r03_two_lanes_ab.txt).
+// BNN_MI355X_LANES=1 forces one lane (A/B); stage profiling and the stage-output hook always run on one lane.
+int lanes_for(int nchunks) {
+  static const bool one = [] { const char *e = std::getenv("BNN_MI355X_LANES"); return e && std::atoi(e) == 1; }();
   const Runtime &r = rt();
-  if (nchunks < 3 || r.profiling || r.debug_last_stage >= 0 || forced == 1) return 1;
-  return (through_ring || forced == 2) ? 2 : 1;
+  return (nchunks >= 3 && !one && !r.profiling && r.debug_last_stage < 0) ? 2 : 1;
 }
 // the second lane's activation workspace for `n` images per pass
 int reserve2(int n) {
@@ -367,6 +376,9 @@ int reserve2(int n) {
   r.cap2 = n;
   return 0;
 }
+// HBM staging buffers of a call on `lanes` lanes: chunk c lands in slot c % slots and runs on lane c & 1 -- with two
+// buffers both would be held by the two chunks in flight and the next copy could not start before one of them ends
+int slots_for(int lanes) { return lanes == 2 ? kStageSlots : 2; }
 // chunk c of a call that runs on `lanes` lanes: its stream
 hipStream_t lane_stream(int c, int lanes) { return (lanes == 2 && (c & 1)) ? rt().stream2 : rt().stream; }
 // all chunks are enqueued: whatever follows on r.stream (the results' way back) comes behind the second lane too
@@ -399,20 +411,23 @@ int chunks_device_ms(int nchunks, double *out) {
   return 0;
 }
 
-// host-buffer path: staging for `chunk` images x 2 and result buffers for `n_total` images
-int reserve_host(int chunk, size_t n_total) {
+// host-buffer path: staging for `chunk` images x `slots` and result buffers for `n_total` images
+int reserve_host(int chunk, size_t n_total, int slots = 2) {
   Runtime &r = rt();
   if (bind_device()) return -1;
-  if (chunk > r.stage_cap) {
+  if (chunk > r.stage_cap || slots > r.stage_slots) {
     HIP_OK(hipDeviceSynchronize());
-    for (int i = 0; i < 2; i++) {
-      (void)hipFree(r.d_images[i]);
-      r.d_images[i] = nullptr;
+    if (chunk < r.stage_cap) chunk = r.stage_cap;
+    if (slots < r.stage_slots) slots = r.stage_slots;
+    for (auto &b : r.d_images) {
+      (void)hipFree(b);
+      b = nullptr;
     }
-    r.stage_cap = 0;
-    for (int i = 0; i < 2; i++)
+    r.stage_cap = r.stage_slots = 0;
+    for (int i = 0; i < slots; i++)
       HIP_OK(hipMalloc(reinterpret_cast<void **>(&r.d_images[i]), (size_t)chunk * r.spec.image_bytes() + 256));
     r.stage_cap = chunk;
+    r.stage_slots = slots;
   }
   if (n_total > r.res_cap) {
     HIP_OK(hipDeviceSynchronize());
@@ -664,18 +679,22 @@ int feed_chunks(const uint8_t *mem, int fd, size_t first, size_t rec, size_t ski
   Runtime &r = rt();
   Feeder &F = feeder();
   if (F.init()) return fail("pinned staging ring: allocation failed");
-  const int nchunks = (int)plan.size() - 1;
+  const int nchunks = (int)plan.size() - 1, nslots = slots_for(lanes);
   if (skip) {  // records go to HBM as they lie on disk; k_strip_records drops the label bytes
-    const size_t need = (size_t)largest_chunk(plan) * rec + 256;
-    if (need > r.d_rec_cap) {
+    size_t need = (size_t)largest_chunk(plan) * rec + 256;
+    if (need > r.d_rec_cap || nslots > r.rec_slots) {
       HIP_OK(hipDeviceSynchronize());
-      for (int i = 0; i < 2; i++) {
-        (void)hipFree(r.d_rec[i]);
-        r.d_rec[i] = nullptr;
+      if (need < r.d_rec_cap) need = r.d_rec_cap;
+      const int want = nslots > r.rec_slots ? nslots : r.rec_slots;
+      for (auto &b : r.d_rec) {
+        (void)hipFree(b);
+        b = nullptr;
       }
       r.d_rec_cap = 0;
-      for (int i = 0; i < 2; i++) HIP_OK(hipMalloc(reinterpret_cast<void **>(&r.d_rec[i]), need));
+      r.rec_slots = 0;
+      for (int i = 0; i < want; i++) HIP_OK(hipMalloc(reinterpret_cast<void **>(&r.d_rec[i]), need));
       r.d_rec_cap = need;
+      r.rec_slots = want;
     }
   }
   std::vector<Feeder::Piece> pieces;
@@ -698,7 +717,7 @@ int feed_chunks(const uint8_t *mem, int fd, size_t first, size_t rec, size_t ski
   };
   for (size_t p = 0; p < pieces.size(); p++) {
     const Feeder::Piece &pc = pieces[p];
-    const int c = pc.chunk, slot = c & 1;
+    const int c = pc.chunk, slot = c % nslots;
     uint8_t st;
     while ((st = F.filled[p].load(std::memory_order_acquire)) == 0) {
       release_done();
@@ -709,8 +728,8 @@ int feed_chunks(const uint8_t *mem, int fd, size_t first, size_t rec, size_t ski
       return fail("input file: read error");
     }
     uint8_t *chunk_dst = skip ? r.d_rec[slot] : r.d_images[slot];
-    // the chunk buffer of two chunks ago: its stages (no label bytes) / its strip kernel (same stream: in order) are done
-    if (pc.off_in_chunk == 0 && c >= 2) {
+    // the chunk that had this buffer before: its stages (no label bytes) / its strip kernel (same stream: in order) are done
+    if (pc.off_in_chunk == 0 && c >= nslots) {
       if (!skip) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));
       // (the second queue writes the same chunk buffer: behind chunk c-2's stages, or -- label bytes -- behind its strip
       // kernel, after which `copied` was recorded)
@@ -728,7 +747,7 @@ int feed_chunks(const uint8_t *mem, int fd, size_t first, size_t rec, size_t ski
     }
     const int base = plan[c], m = plan[c + 1] - plan[c];
     if (skip) {
-      if (c >= 2) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));  // d_images[slot] free again
+      if (c >= nslots) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));  // d_images[slot] free again
       const hipError_t e = launch_strip_records(r.d_rec[slot], (int)rec, (int)skip, r.d_images[slot], m, r.copy_stream);
       if (e != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(e));
     }
@@ -759,8 +778,9 @@ int infer_host(const uint8_t *imgs, int n, int ncls, int32_t *classes, int16_t *
   // (measured, same box: 13.8 ms through the ring, 12.7 ms without, 131 072 CIFAR images).  BNN_MI355X_FEED_HOST=1 forces it.
   static const bool feed_host = std::getenv("BNN_MI355X_FEED_HOST") != nullptr;
   const bool fed = feed_host && nchunks > 1 && use_feeder((size_t)n * isz);
-  const int lanes = lanes_for(nchunks, fed);
-  if (reserve(chunk) || (lanes == 2 && reserve2(chunk)) || reserve_host(chunk, (size_t)n)) return -1;
+  const int lanes = lanes_for(nchunks);
+  const int nslots = slots_for(lanes);
+  if (reserve(chunk) || (lanes == 2 && reserve2(chunk)) || reserve_host(chunk, (size_t)n, nslots)) return -1;
   while ((int)r.time_events.size() < 2 * nchunks) {
     hipEvent_t e;
     HIP_OK(hipEventCreateWithFlags(&e, kTimeEventFlags));
@@ -777,11 +797,11 @@ int infer_host(const uint8_t *imgs, int n, int ncls, int32_t *classes, int16_t *
   };
   if (fed && feed_chunks(imgs, -1, 0, isz, 0, plan, lanes, stages)) return -1;
   for (int c = 0; c < (fed ? 0 : nchunks); c++) {
-    const int base = plan[c], m = plan[c + 1] - plan[c], slot = c & 1;
+    const int base = plan[c], m = plan[c + 1] - plan[c], slot = c % nslots;
     if (nchunks == 1) {  // nothing to overlap: stay on one stream (fewer driver round trips for small calls)
       HIP_OK(hipMemcpyAsync(r.d_images[slot], imgs, (size_t)m * isz, hipMemcpyHostToDevice, r.stream));
     } else {
-      if (c >= 2) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));
+      if (c >= nslots) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));
       HIP_OK(hipMemcpyAsync(r.d_images[slot], imgs + (size_t)base * isz, (size_t)m * isz, hipMemcpyHostToDevice, r.copy_stream));
       HIP_OK(hipEventRecord(r.copied[slot], r.copy_stream));
       HIP_OK(hipStreamWaitEvent(lane_stream(c, lanes), r.copied[slot], 0));
@@ -997,8 +1017,9 @@ int infer_file(const ImageFile &f, int n, int ncls, int32_t *classes, int16_t *s
   // large file: worker threads pread() it into the pinned ring piece by piece (feed_chunks); small: one or a few chunks
   // through a pageable host chunk (stream_file) -- also where the ring cannot be had (no pinned memory to spare): slower, same result
   const bool ring = nchunks > 1 && use_feeder((size_t)n * f.rec) && feeder().init() == 0;
-  const int lanes = lanes_for(nchunks, ring);
-  if (reserve(chunk) || (lanes == 2 && reserve2(chunk)) || reserve_host(chunk, (size_t)n)) return -1;
+  const int lanes = lanes_for(nchunks);
+  const int nslots = slots_for(lanes);
+  if (reserve(chunk) || (lanes == 2 && reserve2(chunk)) || reserve_host(chunk, (size_t)n, nslots)) return -1;
   while ((int)r.time_events.size() < 2 * nchunks) {
     hipEvent_t e;
     HIP_OK(hipEventCreateWithFlags(&e, kTimeEventFlags));
