@@ -145,8 +145,10 @@ int bnn_mi355x_reserve(int max_images);
 
 /* How the entry points that take HOST data cut a call of n images into chunks whose transfer overlaps the
  * previous chunk's stages: small chunks first (the first transfer is what nothing overlaps), each 1.5 times the one
- * before, up to 32 768 images; from_file != 0: inference_multiple(path), which starts at 4 096 images, from_file == 0:
- * inference_buffer / inference_raw, which start at 2 048 (MNIST images: four times as many).  Writes the chunk
+ * before, up to 16 384 images (the LFC nets: 32 768); from_file != 0: inference_multiple(path), which starts at 4 096 images,
+ * from_file == 0: inference_buffer / inference_raw, which start at 2 048 (MNIST images: four times as many).  A call of three
+ * or more chunks runs them alternately on two internal streams ("compute lanes"), each with its own activation workspace;
+ * usecPerImage is then the union of the chunks' device intervals over the images.  Writes the chunk
  * boundaries base[0] = 0 < base[1] < ... < base[k] = n (at most cap of them) and returns k + 1.  Host only; results never
  * depend on the plan (tests/test_gpu_parity.py walks its edges). */
 int bnn_mi355x_chunk_plan(int n_images, int from_file, int *bases, int cap);
