@@ -788,6 +788,7 @@ def test_host_paths_on_two_compute_lanes(tmp_path):
         "k = C.c_int(0); p = net.L.inference_multiple(%r, 10, C.byref(k), None, 0)\n"
         "assert p and (np.ctypeslib.as_array(p, (23001,)) == o.classes_batched(imgs, 10)).all()\n"
         "print('lanes-ok')\n" % (os.path.join(gl.ROOT, "tests"), os.path.join(gl.ROOT, "bnn-pynq_amd"), str(tmp_path / "f.bin"), str(tmp_path / "f.bin").encode()))
-    for lanes in ("1",):
-        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BNN_MI355X_LANES=lanes), capture_output=True, text=True, timeout=600)
-        assert "lanes-ok" in out.stdout, lanes + out.stdout[-1500:] + out.stderr[-3000:]
+    # one lane forced; the pinned ring switched off (the file then streams through pageable host chunks, on two lanes)
+    for knob in ({"BNN_MI355X_LANES": "1"}, {"BNN_MI355X_NO_FEEDER": "1"}):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **knob), capture_output=True, text=True, timeout=600)
+        assert "lanes-ok" in out.stdout, str(knob) + out.stdout[-1500:] + out.stderr[-3000:]
