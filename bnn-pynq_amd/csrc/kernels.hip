@@ -426,8 +426,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_conv0_tile(const uint8_t *__restr
   // and store nothing), 30 tiles per image instead of 29 -- and everything a lane needs to find its bytes and its output
   // word is a wave-uniform term plus a constant of the lane, where tiles of 32 consecutive pixels of the flattened map
   // (29 per image, the first form) cost thirteen VALU instructions of divide-by-30 arithmetic per tile against six now.
-  // Measured gain: 2 % of the stage only (0.502 -> 0.491 ms, profiles/r03_layer0_row_tiles_ab.txt) -- the loop waits for
-  // its MFMA results and LDS fetches more than it issues
+  // Measured gain: 2 % of the stage only (0.502 -> 0.491 ms, profiles/r03_layer0_row_tiles_ab.txt): the instructions
+  // saved are the cheap full-rate kind and there are 3.4 % more tiles
   const uint32_t lane_byte = (uint32_t)(r + h * kL0Plane);
   const bool live = r < 30;
   for (int T = wave; T < cnt * 30; T += kBlock / 64) {
