@@ -377,18 +377,27 @@ def main():
     # run a network as ONE launch (k_lfc_block_s, k_lfc_fused, k_cnv_tail), which per-stage events would switch off: `value`
     # is then timed on the shipped policy without events, and the per-stage breakdown comes from a second pass of the same K
     # steps with events (roofline.stage_times_source says which).
-    events_in_region = is_cnv and a.batch > 32768   # (lfcW1A1 is one k_lfc_block_s launch up to 131 072 images, lfcW1A2 up to 2 048)
+    # Since late round 3 a CNV pass of 16 384 images and more FORKS over two compute lanes (runtime.hip, bnn_mi355x_inference_device:
+    # the halves' kernels overlap, 131 072 images 10.28 -> 10.16 ms); stage events would time overlapping kernels, so profiling
+    # keeps one lane -- and the events move to the second pass for these sizes too, unless BNN_MI355X_LANES=1 (the profile
+    # runs under rocprofv3: one lane, events in the region, kernel names and durations that match the stage table).
+    forks = is_cnv and a.batch >= 16384 and os.environ.get("BNN_MI355X_LANES") != "1"
+    events_in_region = is_cnv and a.batch > 32768 and not forks   # (lfcW1A1 is one k_lfc_block_s launch up to 131 072 images, lfcW1A2 up to 2 048)
     L.bnn_mi355x_profile(1 if events_in_region else 0)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    second_pass_ms = None
     if not events_in_region:
         L.bnn_mi355x_profile(1)
+        barrier()
+        t1 = time.perf_counter()
         for _ in range(a.steps):
             step()
         barrier()
+        second_pass_ms = (time.perf_counter() - t1) / a.steps * 1e3
     stage_ms = (C.c_float * 16)()
     nchunks = C.c_int(0)
     nst = L.bnn_mi355x_profile_read(stage_ms, 16, C.byref(nchunks))
@@ -483,7 +492,10 @@ def main():
                 "algorithmic_bytes_per_image": alg, "images_per_launch": int(imgs_per_launch),
                 "device_ms_per_step": round(dev_ms, 4), "dominant_kernel": dominant,
                 "stage_times_source": "HIP events around every stage inside the timed region" if events_in_region else
-                "second pass of the same steps with HIP events (staged form); `value` is timed without them on the shipped dispatch policy, which may be a single launch at this size",
+                "second pass of the same steps with HIP events (staged form, one compute lane); `value` is timed without them on the shipped "
+                "dispatch policy, which at this size " + ("forks the pass over two compute lanes (the halves' kernels overlap: ms_per_step is "
+                "below the sum of the stages)" if forks else "may be a single launch"),
+                "second_pass_ms_per_step": None if second_pass_ms is None else round(second_pass_ms, 4),
                 "stages_ms": {names[i]: round(per_stage[i], 4) for i in range(nst)}}
     out = {"metric": METRIC if a.network == "cnvW1A1"
            else "images/sec (whole node) %s batch" % a.network,

@@ -57,6 +57,7 @@ namespace bnn {
 namespace {
 
 constexpr int kMaxChunk = 131072;  // images per pass through the stages
+constexpr int kForkMin = 16384;     // images: a device-pointer pass of a CNV net of this size and more forks over the two compute lanes
 constexpr int kStageSlots = 4;      // HBM staging buffers of the host paths: two on one compute lane, four on two
 // Events that only TIME device work: a device-scope release at the record point instead of a flush to system scope
 // ("useful to obtain more precise timings of commands between events", hip_runtime_api.h).  Nothing on the host reads
@@ -172,6 +173,10 @@ struct Runtime {
   hipEvent_t ws_event = nullptr;
   hipStream_t ws_last = nullptr;  // the caller's stream of that call (may be the null stream: hence the flag)
   bool ws_pending = false;
+  // (both workspaces since such a call may fork over the two lanes: the library's own two streams each remember the last
+  // hand-over they have waited for, a caller's stream waits whenever one is pending)
+  uint64_t ws_gen = 0, ws_seen[2] = {0, 0};
+  hipEvent_t fork_ev = nullptr;
   hipEvent_t copied[kStageSlots] = {}, consumed[kStageSlots] = {};
   std::vector<hipEvent_t> time_events;
   // file path: records as they lie on disk, two host chunks (filled by reader threads) and two HBM chunks
@@ -229,6 +234,7 @@ int bind_device() {
       HIP_OK(hipEventCreateWithFlags(&r.consumed[i], hipEventDisableTiming));
     }
     HIP_OK(hipEventCreateWithFlags(&r.ws_event, hipEventDisableTiming));
+    HIP_OK(hipEventCreateWithFlags(&r.fork_ev, hipEventDisableTiming));
   }
   return 0;
 }
@@ -443,16 +449,13 @@ int reserve_host(int chunk, size_t n_total, int slots = 2) {
   return 0;
 }
 
-// enqueue one chunk (n <= cap) whose images are already in HBM
-// t0 / t1 (optional): this chunk's device time is t0 -> t1 (kernels.h)
-int enqueue(const uint8_t *d_imgs, int n, int ncls, int32_t *d_classes, int16_t *d_scores, uint64_t *d_words,
-            hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr, int lane = 0) {
+// An earlier device-pointer call on another stream may still own the activation workspaces: work about to be queued on
+// `s` waits for its end first.
+int settle_handover(hipStream_t s) {
   Runtime &r = rt();
-  hipError_t e;
-  hipEvent_t *evs = nullptr;
-  void *const ws0 = lane ? r.buf0b : r.buf0, *const ws1 = lane ? r.buf1b : r.buf1;
-  // (the second lane's workspace is used by host-path calls only, and those drain their streams before they return)
-  if (lane == 0 && r.ws_pending && r.ws_last != s) {  // an earlier device-pointer call on another stream may still own the workspace
+  const int own = s == r.stream ? 0 : (s == r.stream2 ? 1 : -1);
+  if (own >= 0 ? (r.ws_seen[own] == r.ws_gen || r.ws_last == s) : (!r.ws_pending || r.ws_last == s)) return 0;
+  {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
     // A capturing stream must not wait on an event recorded outside its capture (the capture would be invalidated, or
@@ -470,8 +473,21 @@ int enqueue(const uint8_t *d_imgs, int n, int ncls, int32_t *d_classes, int16_t 
     } else {
       HIP_OK(hipStreamWaitEvent(s, r.ws_event, 0));
     }
-    r.ws_pending = false;
   }
+  if (own >= 0) r.ws_seen[own] = r.ws_gen;
+  else r.ws_pending = false;
+  return 0;
+}
+
+// enqueue one chunk (n <= cap) whose images are already in HBM
+// t0 / t1 (optional): this chunk's device time is t0 -> t1 (kernels.h)
+int enqueue(const uint8_t *d_imgs, int n, int ncls, int32_t *d_classes, int16_t *d_scores, uint64_t *d_words,
+            hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr, int lane = 0) {
+  Runtime &r = rt();
+  hipError_t e;
+  hipEvent_t *evs = nullptr;
+  void *const ws0 = lane ? r.buf0b : r.buf0, *const ws1 = lane ? r.buf1b : r.buf1;
+  if (settle_handover(s)) return -1;
   if (r.profiling) {
     const int need = (r.spec.is_cnv ? kCnvStages : kLfcStages) + 1;
     if (r.prof_used == r.prof_sets.size()) {
@@ -1595,24 +1611,48 @@ int bnn_mi355x_inference_device(const void *d_images, int n_images, int number_c
     if (reserve_host(1, (size_t)n_images)) return -1;
     d_words = r.d_words;
   }
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &capturing) != hipSuccess) capturing = hipStreamCaptureStatusNone;
   for (int base = 0; base < n_images; base += kMaxChunk) {
     const int m = (n_images - base < kMaxChunk) ? n_images - base : kMaxChunk;
-    if (reserve(m)) return -1;
-    if (enqueue(static_cast<const uint8_t *>(d_images) + (size_t)base * isz, m, number_class,
-                d_classes ? d_classes + base : nullptr, d_scores ? d_scores + (size_t)base * 64 : nullptr,
-                d_words ? d_words + base : nullptr, s))
+    const uint8_t *img = static_cast<const uint8_t *>(d_images) + (size_t)base * isz;
+    int32_t *cls = d_classes ? d_classes + base : nullptr;
+    int16_t *sc = d_scores ? d_scores + (size_t)base * 64 : nullptr;
+    uint64_t *wd = d_words ? d_words + base : nullptr;
+    // A pass of a CNV net forks over the two compute lanes: first half on the caller's stream, second half on the
+    // library's second stream (its own activation workspace), joined before the call returns -- one half's launch gaps
+    // and kernel tails are filled by the other's kernels.  tools/two_lane_probe.py (HALVES=2), profiles/
+    // r03_device_call_fork_probe.txt: 131 072 images 10.28 -> 10.16 ms, 65 536 5.26 -> 5.13, 32 768 2.69 -> 2.60, 20 000
+    // 1.66 -> 1.63; 10 000 images and the LFC nets (one launch per pass) lose, four or eight pieces gain less.  Not while the
+    // caller's stream is being captured into a graph, nor with stage profiling on (the stage events would time overlapping
+    // kernels), nor under BNN_MI355X_LANES=1.
+    const bool fork = r.spec.is_cnv && m >= kForkMin && lanes_for(3) == 2 && capturing == hipStreamCaptureStatusNone;
+    if (!fork) {
+      if (reserve(m) || enqueue(img, m, number_class, cls, sc, wd, s)) return -1;
+      continue;
+    }
+    const int h = ((m / 2) + 255) & ~255;  // whole blocks of 256 images in the first half
+    if (reserve(h) || reserve2(m - h)) return -1;
+    if (settle_handover(s)) return -1;  // (before the fork: the second lane inherits the wait through the fork event)
+    HIP_OK(hipEventRecord(r.fork_ev, s));
+    HIP_OK(hipStreamWaitEvent(r.stream2, r.fork_ev, 0));
+    r.ws_seen[1] = r.ws_gen;
+    if (enqueue(img, h, number_class, cls, sc, wd, s)) return -1;
+    if (enqueue(img + (size_t)h * isz, m - h, number_class, cls ? cls + h : nullptr, sc ? sc + (size_t)h * 64 : nullptr, wd ? wd + h : nullptr,
+                r.stream2, nullptr, nullptr, 1))
       return -1;
+    HIP_OK(hipEventRecord(r.lane2_done, r.stream2));
+    HIP_OK(hipStreamWaitEvent(s, r.lane2_done, 0));
   }
   // mark the end of this call's use of the shared workspace (not while the stream is being captured into a
   // graph: a replayed graph is serialised by its own stream, and the caller must not replay it concurrently
   // with other calls into this library -- include/bnn_mi355x.h)
   if (n_images > 0 && s != r.stream) {
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cap) != hipSuccess) cap = hipStreamCaptureStatusNone;
-    if (cap == hipStreamCaptureStatusNone) {
+    if (capturing == hipStreamCaptureStatusNone) {
       HIP_OK(hipEventRecord(r.ws_event, s));
       r.ws_last = s;
       r.ws_pending = true;
+      r.ws_gen++;
     }
   }
   return 0;

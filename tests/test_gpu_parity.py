@@ -792,3 +792,53 @@ def test_host_paths_on_two_compute_lanes(tmp_path):
     for knob in ({"BNN_MI355X_LANES": "1"}, {"BNN_MI355X_NO_FEEDER": "1"}):
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **knob), capture_output=True, text=True, timeout=600)
         assert "lanes-ok" in out.stdout, str(knob) + out.stdout[-1500:] + out.stderr[-3000:]
+
+
+@pytest.mark.parametrize("network", ["cnvW1A1", "cnvW2A2"])
+def test_device_call_forks_over_two_lanes(network):
+    """a device-pointer pass of 16 384 CNV images and more runs its halves on two streams with two activation workspaces
+    and joins them before the caller's stream goes on (bnn_mi355x_inference_device): scores and classes of every image
+    either side of the limit and at ragged sizes against the restatement; calls alternating over three caller streams
+    without host synchronisation between them (each must wait for BOTH lanes of the one before); a host-buffer call
+    issued while forked device work is still in flight (its second lane shares the second workspace); the same batch
+    through a captured graph (one lane) gives the same classes"""
+    import torch
+    net, o = gpu_net(network, "cifar10"), oracle(network, "cifar10")
+    L = net.L
+    for n in (16383, 16384, 16385, 20011, 33001):
+        imgs = rand_images(network, n, 500 + n % 7)
+        d = torch.from_numpy(imgs).cuda()
+        cls = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+        sc = torch.zeros((n, 64), dtype=torch.int16, device="cuda")
+        assert L.bnn_mi355x_inference_device(d.data_ptr(), n, 10, cls.data_ptr(), sc.data_ptr(), None, None) == 0
+        torch.cuda.synchronize()
+        assert (sc.cpu().numpy() == o.scores_fast(imgs)).all(), (network, n)
+        assert (cls.cpu().numpy() == o.classes_batched(imgs, 10)).all(), (network, n)
+    n = 20000
+    batches = [rand_images(network, n, 40 + k) for k in range(3)]
+    want = [o.classes_batched(b, 10) for b in batches]
+    dev = [torch.from_numpy(b).cuda() for b in batches]
+    out = [torch.full((n,), -1, dtype=torch.int32, device="cuda") for _ in range(3)]
+    streams = [torch.cuda.Stream().cuda_stream, None, torch.cuda.Stream().cuda_stream]
+    torch.cuda.synchronize()
+    for rep in range(4):
+        for k in range(3):
+            s = streams[(rep + k) % 3]
+            assert L.bnn_mi355x_inference_device(dev[k].data_ptr(), n, 10, out[k].data_ptr(), None, None, s) == 0
+    # no synchronisation: the host-buffer call below must itself wait for the forked work on both of its lanes
+    host = rand_images(network, 9001, 77)
+    assert (net.raw(host) == o.scores_fast(host)).all()
+    torch.cuda.synchronize()
+    for k in range(3):
+        assert (out[k].cpu().numpy() == want[k]).all(), (network, k)
+    # captured into a graph (one lane while capturing) and replayed
+    s = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    cap = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    assert L.bnn_mi355x_reserve(n) == 0              # (the forked calls above sized the first workspace for a half)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=s):
+        assert L.bnn_mi355x_inference_device(dev[0].data_ptr(), n, 10, cap.data_ptr(), None, None, torch.cuda.current_stream().cuda_stream) == 0
+    g.replay()
+    torch.cuda.synchronize()
+    assert (cap.cpu().numpy() == want[0]).all()

@@ -29,9 +29,14 @@ for L in (A, B):
     L.load_parameters(pdir)
 isz = A.bnn_mi355x_image_bytes()
 bases = (C.c_int * 256)()
-for from_file in (0, 1):
+halves = os.environ.get("HALVES")  # HALVES=1: instead of the chunk plans, the batch cut into two equal halves (what a fork-join inside
+                                   # bnn_mi355x_inference_device would run), against the same batch as one call
+for from_file in ((0,) if halves else (0, 1)):
     k = A.bnn_mi355x_chunk_plan(n, from_file, bases, 256)
     plan = [bases[i] for i in range(k)]
+    if halves:  # HALVES=k: k equal pieces (multiples of 256 images)
+        k = max(int(halves), 2)
+        plan = [min(((n * i // k) + 255) & ~255, n) for i in range(k)] + [n]
     imgs = torch.randint(0, 256, (n, isz), dtype=torch.uint8, device="cuda")
     cls = torch.zeros(n, dtype=torch.int32, device="cuda")
     s = [torch.cuda.Stream(), torch.cuda.Stream()]
