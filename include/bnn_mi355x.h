@@ -129,7 +129,10 @@ int bnn_mi355x_inference_raw(const uint8_t *images, int n_images, int16_t *score
  * a misaligned pointer is refused (-1 + last_error), nothing is launched.  The workspace grows on demand (which
  * synchronises); call bnn_mi355x_reserve first to keep the call fully
  * asynchronous / graph-capturable.  Returns 0 on success.
- * One activation workspace per library instance: calls are serialised on the device -- a call on another
+ * A pass of a CNV net of 16 384 images and more runs its second half on a stream of the library's own (second activation
+ * workspace) and joins it into `hip_stream` before anything queued after the call can run: to the caller the call is still
+ * one in-order piece of work on `hip_stream` (not while that stream is being captured, then everything stays on it).
+ * The activation workspaces belong to the library instance: calls are serialised on the device -- a call on another
  * stream than the previous one first waits (hipStreamWaitEvent) for that call's kernels -- so they never
  * race, but they do not overlap either (a stream handed in here must stay alive until its work is done: the
  * previous call's stream is recognised by its handle).  While `hip_stream` is being captured into a graph the
