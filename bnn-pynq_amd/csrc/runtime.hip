@@ -1406,7 +1406,14 @@ int bnn_mi355x_inference_raw(const uint8_t *images, int n_images, int16_t *score
   return infer_host(images, n_images, 64, nullptr, scores, words, usecPerImage);
 }
 
-int bnn_mi355x_reserve(int max_images) { return ready() ? reserve(max_images) : -1; }
+int bnn_mi355x_reserve(int max_images) {
+  if (!ready() || reserve(max_images)) return -1;
+  // (a CNV pass of kForkMin images and more runs its second half on the second lane: size that workspace now as well, so
+  // that the call itself stays free of allocations)
+  const int m = max_images < kMaxChunk ? max_images : kMaxChunk;
+  if (rt().spec.is_cnv && m >= kForkMin && lanes_for(3) == 2) return reserve2((m + 1) / 2);  // (>= the second half of any pass up to m)
+  return 0;
+}
 
 #ifdef BNN_LFC_STAMPS
 // diagnostic build only: 1024 blocks x 8 wall-clock stamps (100 MHz) of the last k_lfc_block_s launch
