@@ -743,12 +743,40 @@ def test_file_abi_either_side_of_the_pinned_ring_threshold(n, tmp_path):
         assert (got == want).all()
 
 
+def _one_lane_reference(net, imgs):
+    """raw outputs (CNV: scores [n,64], LFC: words [n]) and classes of `imgs` through bnn_mi355x_inference_device in slices
+    of 8 000 images on the null stream: below every fork / lane limit, i.e. the plain one-stream path that the other tests
+    compare with the restatement image by image"""
+    import torch
+    n = imgs.shape[0]
+    d = torch.from_numpy(imgs).cuda()
+    cls = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    raw = torch.zeros((n, 64), dtype=torch.int16, device="cuda") if net.is_cnv else torch.zeros(n, dtype=torch.int64, device="cuda")
+    for b in range(0, n, 8000):
+        m = min(8000, n - b)
+        rc = net.L.bnn_mi355x_inference_device(d.data_ptr() + b * net.isz, m, 10, cls.data_ptr() + 4 * b,
+                                               raw.data_ptr() + 128 * b if net.is_cnv else None,
+                                               None if net.is_cnv else raw.data_ptr() + 8 * b, None)
+        assert rc == 0
+    torch.cuda.synchronize()
+    r = raw.cpu().numpy()
+    return (r if net.is_cnv else r.view(np.uint64)), cls.cpu().numpy()
+
+
+def _oracle_sample(o, imgs, classes, edges, seed):
+    """the restatement on the images either side of `edges` and on 200 random ones"""
+    n = imgs.shape[0]
+    pick = sorted({min(max(e + k, 0), n - 1) for e in edges for k in (-2, -1, 0, 1)} | set(np.random.default_rng(seed).choice(n, 200, replace=False).tolist()))
+    assert (classes[pick] == o.classes_batched(imgs[pick], 10)).all()
+
+
 def test_host_paths_on_two_compute_lanes(tmp_path):
     """a host-path call of three or more chunks alternates them over two streams, two activation workspaces and four
-    staging buffers (runtime.hip, "Two compute lanes"): classes / raw scores of every image against the restatement for the
+    staging buffers (runtime.hip, "Two compute lanes"): classes / raw outputs of EVERY image equal to the one-stream device
+    path's (slices of 8 000 images), and the restatement's on the images at every chunk edge and a random sample, for the
     file and the buffer entry points -- CNV (label bytes stripped on the device) and LFC, ragged last chunk, repeated calls
     (the lanes' buffers are reused) --, `usecPerImage` the union of the chunks' device intervals (positive, below the wall
-    time); the same with one lane forced (BNN_MI355X_LANES=1)"""
+    time); the same with one lane forced (BNN_MI355X_LANES=1) and with the pinned ring off"""
     import subprocess
     import sys
     import time
@@ -756,9 +784,14 @@ def test_host_paths_on_two_compute_lanes(tmp_path):
         net, o = gpu_net(network, dataset), oracle(network, dataset)
         k = C.c_int(0)
         bases = (C.c_int * 64)()
-        assert net.L.bnn_mi355x_chunk_plan(n, 1, bases, 64) >= 4         # three or more chunks, > 24 MB: ring-fed, two lanes
         imgs = rand_images(network, n, 77)
-        want = o.classes_batched(imgs, 10)
+        want_raw, want = _one_lane_reference(net, imgs)
+        edges = set()
+        for from_file in (0, 1):
+            nb = net.L.bnn_mi355x_chunk_plan(n, from_file, bases, 64)
+            assert nb >= 4                                            # three or more chunks: two lanes (files: > 24 MB, ring-fed)
+            edges |= {bases[i] for i in range(nb)}
+        _oracle_sample(o, imgs, want, edges, n)
         path = str(tmp_path / (network + ".bin"))
         with open(path, "wb") as f:
             if net.is_cnv:
@@ -775,18 +808,18 @@ def test_host_paths_on_two_compute_lanes(tmp_path):
             net.L.free_results(p)
             assert (got == want).all(), (network, "file", rep)
             assert 0 < usec.value * n < wall_us, (network, usec.value * n, wall_us)
-        assert net.L.bnn_mi355x_chunk_plan(n, 0, bases, 64) >= 4         # the buffer's plan as well
-        got = net.raw(imgs)
-        assert (got == (o.scores_fast(imgs) if net.is_cnv else o.words_fast(imgs))).all(), network
+        for rep in range(2):
+            assert (net.raw(imgs) == want_raw).all(), (network, "buffer", rep)
     code = (
         "import sys, ctypes as C, numpy as np; sys.path[:0] = [%r, %r]\n"
         "import gpu_lib as gl, oracle_lib as ol\n"
         "net = gl.Net('cnvW1A1', 'cifar10'); o = ol.Oracle('cnvW1A1', ol.param_dir('cifar10', 'cnvW1A1'))\n"
-        "imgs = np.random.default_rng(5).integers(0, 256, (23001, 3072), dtype=np.uint8)\n"
-        "for rep in range(2): assert (net.raw(imgs) == o.scores_fast(imgs)).all()\n"
-        "r = np.empty((23001, 3073), np.uint8); r[:, 0] = 1; r[:, 1:] = imgs; open(%r, 'wb').write(r.tobytes())\n"
+        "imgs = np.random.default_rng(5).integers(0, 256, (12001, 3072), dtype=np.uint8)\n"
+        "want = o.scores_fast(imgs)\n"
+        "for rep in range(2): assert (net.raw(imgs) == want).all()\n"
+        "r = np.empty((12001, 3073), np.uint8); r[:, 0] = 1; r[:, 1:] = imgs; open(%r, 'wb').write(r.tobytes())\n"
         "k = C.c_int(0); p = net.L.inference_multiple(%r, 10, C.byref(k), None, 0)\n"
-        "assert p and (np.ctypeslib.as_array(p, (23001,)) == o.classes_batched(imgs, 10)).all()\n"
+        "assert p and (np.ctypeslib.as_array(p, (12001,)) == o.classes_batched(imgs, 10)).all()\n"
         "print('lanes-ok')\n" % (os.path.join(gl.ROOT, "tests"), os.path.join(gl.ROOT, "bnn-pynq_amd"), str(tmp_path / "f.bin"), str(tmp_path / "f.bin").encode()))
     # one lane forced; the pinned ring switched off (the file then streams through pageable host chunks, on two lanes)
     for knob in ({"BNN_MI355X_LANES": "1"}, {"BNN_MI355X_NO_FEEDER": "1"}):
@@ -797,26 +830,29 @@ def test_host_paths_on_two_compute_lanes(tmp_path):
 @pytest.mark.parametrize("network", ["cnvW1A1", "cnvW2A2"])
 def test_device_call_forks_over_two_lanes(network):
     """a device-pointer pass of 16 384 CNV images and more runs its halves on two streams with two activation workspaces
-    and joins them before the caller's stream goes on (bnn_mi355x_inference_device): scores and classes of every image
-    either side of the limit and at ragged sizes against the restatement; calls alternating over three caller streams
-    without host synchronisation between them (each must wait for BOTH lanes of the one before); a host-buffer call
-    issued while forked device work is still in flight (its second lane shares the second workspace); the same batch
-    through a captured graph (one lane) gives the same classes"""
+    and joins them before the caller's stream goes on (bnn_mi355x_inference_device): scores and classes of EVERY image
+    equal to the one-stream path's (slices of 8 000 images), and the restatement's around the split and on a random
+    sample, either side of the limit and at ragged sizes; calls alternating over three caller streams without host
+    synchronisation between them (each must wait for BOTH lanes of the one before); a host-buffer call issued while
+    forked device work is still in flight (its second lane shares the second workspace); the same batch through a
+    captured graph (one lane) gives the same classes"""
     import torch
     net, o = gpu_net(network, "cifar10"), oracle(network, "cifar10")
     L = net.L
     for n in (16383, 16384, 16385, 20011, 33001):
         imgs = rand_images(network, n, 500 + n % 7)
+        want_sc, want = _one_lane_reference(net, imgs)
         d = torch.from_numpy(imgs).cuda()
         cls = torch.full((n,), -1, dtype=torch.int32, device="cuda")
         sc = torch.zeros((n, 64), dtype=torch.int16, device="cuda")
         assert L.bnn_mi355x_inference_device(d.data_ptr(), n, 10, cls.data_ptr(), sc.data_ptr(), None, None) == 0
         torch.cuda.synchronize()
-        assert (sc.cpu().numpy() == o.scores_fast(imgs)).all(), (network, n)
-        assert (cls.cpu().numpy() == o.classes_batched(imgs, 10)).all(), (network, n)
+        assert (sc.cpu().numpy() == want_sc).all(), (network, n)
+        assert (cls.cpu().numpy() == want).all(), (network, n)
+        _oracle_sample(o, imgs, want, {((n // 2) + 255) & ~255}, n)
     n = 20000
     batches = [rand_images(network, n, 40 + k) for k in range(3)]
-    want = [o.classes_batched(b, 10) for b in batches]
+    want = [_one_lane_reference(net, b)[1] for b in batches]
     dev = [torch.from_numpy(b).cuda() for b in batches]
     out = [torch.full((n,), -1, dtype=torch.int32, device="cuda") for _ in range(3)]
     streams = [torch.cuda.Stream().cuda_stream, None, torch.cuda.Stream().cuda_stream]
