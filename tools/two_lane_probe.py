@@ -37,6 +37,8 @@ for from_file in ((0,) if halves else (0, 1)):
     if halves:  # HALVES=k: k equal pieces (multiples of 256 images)
         k = max(int(halves), 2)
         plan = [min(((n * i // k) + 255) & ~255, n) for i in range(k)] + [n]
+        if os.environ.get("SPLIT"):  # SPLIT=0.4: two pieces, the first 40 % of the batch
+            plan = [0, (int(n * float(os.environ["SPLIT"])) + 255) & ~255, n]
     imgs = torch.randint(0, 256, (n, isz), dtype=torch.uint8, device="cuda")
     cls = torch.zeros(n, dtype=torch.int32, device="cuda")
     s = [torch.cuda.Stream(), torch.cuda.Stream()]
