@@ -13,7 +13,8 @@ import oracle_lib as ol
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 only = sys.argv[2] if len(sys.argv) > 2 else "all"
 edges = {"cnv": [1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 1500, 2049,
-                 8185, 8191, 8192, 8193, 8199, 9001],      # layer 0: lane per pixel below 8 192 images, blocks of 8 from there
+                 8185, 8191, 8192, 8193, 8199, 9001,       # layer 0: lane per pixel below 8 192 images, blocks of 8 from there
+                 16383, 16384, 16385, 16641],             # the device call forks over two lanes from 16 384 images
          "lfc": [1, 2, 63, 65, 255, 257, 511, 513, 1023, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 6000, 8191, 12289, 20001,
                  32767, 32768, 32769, 33000]}
 for net, ds in (("cnvW1A1", "cifar10"), ("cnvW1A2", "cifar10"), ("cnvW2A2", "cifar10"), ("lfcW1A1", "mnist"), ("lfcW1A2", "mnist")) if only in ("all", "sizes") else ():
