@@ -21,11 +21,14 @@ is_cnv = net.startswith("cnv")
 pdir = gl.param_dir("cifar10" if is_cnv else "mnist", net).encode()
 A = gl.load(net)
 tmp = tempfile.mkdtemp()
-shutil.copy(gl.lib_path(net), os.path.join(tmp, "second_lane.so"))
-B = C.CDLL(os.path.join(tmp, "second_lane.so"))
-abi.declare_legacy(B)
-abi.declare_extensions(B)
-for L in (A, B):
+libs = [A]
+for i in range(max(int(os.environ.get("LANES", "2")), 2) - 1):   # LANES=3: a third copy of the library, three lanes
+    shutil.copy(gl.lib_path(net), os.path.join(tmp, "lane%d.so" % (i + 2)))
+    B = C.CDLL(os.path.join(tmp, "lane%d.so" % (i + 2)))
+    abi.declare_legacy(B)
+    abi.declare_extensions(B)
+    libs.append(B)
+for L in libs:
     L.load_parameters(pdir)
 isz = A.bnn_mi355x_image_bytes()
 bases = (C.c_int * 256)()
@@ -41,19 +44,19 @@ for from_file in ((0,) if halves else (0, 1)):
             plan = [0, (int(n * float(os.environ["SPLIT"])) + 255) & ~255, n]
     imgs = torch.randint(0, 256, (n, isz), dtype=torch.uint8, device="cuda")
     cls = torch.zeros(n, dtype=torch.int32, device="cuda")
-    s = [torch.cuda.Stream(), torch.cuda.Stream()]
+    s = [torch.cuda.Stream() for _ in libs]
 
     def walk(lanes):
         for c in range(len(plan) - 1):
             lane = c % lanes
-            L = (A, B)[lane]
+            L = libs[lane]
             m = plan[c + 1] - plan[c]
             rc = L.bnn_mi355x_inference_device(C.c_void_p(imgs.data_ptr() + plan[c] * isz), m, 10, C.c_void_p(cls.data_ptr() + 4 * plan[c]), None, None,
                                                C.c_void_p(s[lane].cuda_stream))
             assert rc == 0
         torch.cuda.synchronize()
 
-    for lanes in (1, 2, 1, 2):
+    for lanes in (1, len(libs), 1, len(libs)):
         walk(lanes); walk(lanes)
         ref = cls.clone() if lanes == 1 else ref
         t = []
