@@ -185,11 +185,12 @@ def issue_floor_cycles(network):
     kind, prec = network[:3], network[3:]
     cyc = WORD_MACS[kind] * PAIRS_PER_WORD[prec] * PAIR_CYC_OF[prec]
     if kind == "cnv":
-        # layer 0 runs on the matrix pipe (k_conv0_tile); what stays on the integer pipe per 32-pixel tile and lane: one
-        # v_alignbit per result (32), one v_alignbyte per 3-tap run (5), shifts / merge / store and addressing (~13); 29
-        # tiles of 64 lanes per image, + quantising every input byte once (768 dwords x 7)
+        # layer 0 runs on the matrix pipe (k_conv0_tile); what stays on the integer pipe per tile (one output row: 30 live
+        # pixel lanes of 32) and lane: one v_alignbit per result (32), one v_alignbyte per 3-tap run (5), shifts / merge /
+        # store and addressing (~14): 51 as built; 30 row tiles of 64 lanes per image, + quantising every input byte once
+        # (768 dwords x 7)
         # (2-bit activations: a second threshold = 32 more results per tile and lane)
-        cyc += (29 * 64 * (50 + (32 if prec.endswith("A2") else 0)) + 768 * 7) * SLOT_CYC
+        cyc += (30 * 64 * (51 + (32 if prec.endswith("A2") else 0)) + 768 * 7) * SLOT_CYC
     return cyc / 64.0                                # 64 lanes per wave instruction
 
 

@@ -18,7 +18,8 @@ EXT = ["bnn_mi355x_network", "bnn_mi355x_image_bytes", "bnn_mi355x_last_error", 
        "bnn_mi355x_reserve", "bnn_mi355x_set_fault_seed", "bnn_mi355x_last_faults", "bnn_mi355x_plan_faults",
        "bnn_mi355x_pack_params_faulty", "bnn_mi355x_debug_stage_output", "bnn_mi355x_profile",
        "bnn_mi355x_profile_read", "bnn_mi355x_stage_name", "bnn_mi355x_thumbnail_size", "bnn_mi355x_images_to_cifar",
-       "bnn_mi355x_params_bytes", "bnn_mi355x_import_params_device", "bnn_mi355x_params_crc", "bnn_mi355x_chunk_plan"]
+       "bnn_mi355x_params_bytes", "bnn_mi355x_import_params_device", "bnn_mi355x_params_crc", "bnn_mi355x_chunk_plan",
+       "bnn_mi355x_binarize_pack"]
 
 
 def lib_path(network, runtime="python_sw", lib_dir=None):
@@ -65,6 +66,7 @@ def declare_extensions(L):
                                               C.c_void_p]
     L.bnn_mi355x_reserve.argtypes = [C.c_int]
     L.bnn_mi355x_chunk_plan.argtypes = [C.c_int, C.c_int, ip, C.c_int]
+    L.bnn_mi355x_binarize_pack.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.bnn_mi355x_set_fault_seed.argtypes = [C.c_ulonglong]
     L.bnn_mi355x_last_faults.argtypes = [ip, C.c_int]
     L.bnn_mi355x_plan_faults.argtypes = [C.c_ulonglong, C.c_int, C.c_uint, C.c_int, C.c_int, ip, C.c_uint, ip, C.c_int]

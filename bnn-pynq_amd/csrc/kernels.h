@@ -27,7 +27,8 @@ struct CnvLaunch {
 };
 
 struct LfcLaunch {
-  const uint8_t *images;      // device, n x 784 bytes
+  const uint8_t *images;      // device, n x 784 bytes -- or, `packed`, n x 13 binarised words (csrc/pack_inputs.h), 8-byte aligned
+  bool packed;
   int n;
   void *buf0, *buf1;
   const uint32_t *rows[4];
@@ -42,6 +43,10 @@ struct LfcLaunch {
   // timestamps (hipExtLaunchKernelGGL) -- what a kernel trace reports for it -- instead of two more packets around
   // it, whose processing would be booked as compute (3.5 us on a 7 us kernel).
   hipEvent_t t0, t1;
+  // t0 / t1 may be bound to the one dispatch (above).  Only for a call that is ONE chunk: hipEventElapsedTime between
+  // such events of DIFFERENT dispatches is not an interval a multi-chunk call could place its chunks by; those get
+  // ordinary recorded events around the launch.
+  bool t_dispatch;
 };
 
 // layer-0 MFMA table (packed_params.h): the tile-form operands sit behind the pixel-form ones

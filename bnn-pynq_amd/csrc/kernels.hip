@@ -41,6 +41,9 @@
 #include <type_traits>
 
 #include "kernels.h"
+#include "packed_params.h"
+static_assert(bnn::kL0TileOffset == (int)bnn::kL0MfmaTileOffset && bnn::kL0BigBytes == (int)bnn::kL0MfmaBigBytes,
+              "k_conv0_tile's operand offsets must be the ones packed_params.cpp writes the layer-0 table by");
 
 namespace bnn {
 namespace {
@@ -1487,7 +1490,9 @@ __device__ __forceinline__ int lfc_q_tb(const uint64_t (&w)[KW], const uint64_t 
   return 2 * m - nz;
 }
 
-template <int IPB>
+// PACKED: `imgs` holds 13 binarised words per image (the host entry points binarise like the reference does,
+// csrc/pack_inputs.h) instead of 784 pixels
+template <int IPB, bool PACKED = false>
 __global__ __launch_bounds__(1024) void k_lfc_fused_a2(const uint8_t *__restrict__ imgs, uint64_t *__restrict__ words,
                                                         int32_t *__restrict__ classes, const uint32_t *__restrict__ r0,
                                                         const uint32_t *__restrict__ r1, const uint32_t *__restrict__ r2,
@@ -1499,16 +1504,22 @@ __global__ __launch_bounds__(1024) void k_lfc_fused_a2(const uint8_t *__restrict
   int a0, b0, a1, b1, a2, b2, a3 = 0, b3 = 0;
   // (pixels first: see k_lfc_fused)
   uint8_t px[IPB];
+  uint64_t pw[IPB];
 #pragma unroll
   for (int i = 0; i < IPB; i++) {
     const int img = img0 + i < n_images ? img0 + i : n_images - 1;
-    px[i] = imgs[(size_t)img * 784 + (t < 784 ? t : 783)];
+    if constexpr (PACKED) pw[i] = reinterpret_cast<const uint64_t *>(imgs)[(size_t)img * 13 + (t < 13 ? t : 12)];
+    else px[i] = imgs[(size_t)img * 784 + (t < 784 ? t : 783)];
   }
   lfc_load_row2<13>(r0, t, w0, a0, b0);
 #pragma unroll
   for (int i = 0; i < IPB; i++) {
-    const uint64_t word = __ballot(px[i] >= 128 && t < 784);
-    if (lane == 0) in0[i][wave] = word;
+    if constexpr (PACKED) {
+      if (t < 16) in0[i][t] = t < 13 ? pw[i] : 0;
+    } else {
+      const uint64_t word = __ballot(px[i] >= 128 && t < 784);
+      if (lane == 0) in0[i][wave] = word;
+    }
   }
   lfc_load_row2<16>(r1, t, w1, a1, b1);
   __syncthreads();
@@ -1571,7 +1582,7 @@ __device__ __forceinline__ bool lfc_fires(const uint64_t (&w)[KW], int t, const 
   return m < t;
 }
 
-template <int IPB>
+template <int IPB, bool PACKED = false>
 __global__ __launch_bounds__(1024) void k_lfc_fused(const uint8_t *__restrict__ imgs, uint64_t *__restrict__ words,
                                                      int32_t *__restrict__ classes, const uint32_t *__restrict__ r0,
                                                      const uint32_t *__restrict__ r1, const uint32_t *__restrict__ r2,
@@ -1590,17 +1601,24 @@ __global__ __launch_bounds__(1024) void k_lfc_fused(const uint8_t *__restrict__ 
   // the pixels are requested first: vector loads return in order, so waiting for them does not mean waiting for rows
   // (against the round-2 order -- row 0, then the pixels behind a branch -- no measurable difference: 8.7-9.3 vs 8.8-9.1 us)
   uint8_t px[IPB];
+  uint64_t pw[IPB];
 #pragma unroll
   for (int i = 0; i < IPB; i++) {
     const int img = img0 + i < n_images ? img0 + i : n_images - 1;  // ragged tail: duplicate, store guarded
-    px[i] = imgs[(size_t)img * 784 + (t < 784 ? t : 783)];  // (unconditional: a branch would put the wait in front of the row loads)
+    // (unconditional: a branch would put the wait in front of the row loads)
+    if constexpr (PACKED) pw[i] = reinterpret_cast<const uint64_t *>(imgs)[(size_t)img * 13 + (t < 13 ? t : 12)];
+    else px[i] = imgs[(size_t)img * 784 + (t < 784 ? t : 783)];
   }
   lfc_load_row<13>(r0, t, w0, t0);
   // binarizeAndPack: bit i = (pixel i >= 128); pixels 784..831 are padding (0)
 #pragma unroll
   for (int i = 0; i < IPB; i++) {
-    const uint64_t word = __ballot(px[i] >= 128 && t < 784);
-    if (lane == 0) act[0][i][wave] = word;  // waves 13..15 write zeros
+    if constexpr (PACKED) {
+      if (t < 16) act[0][i][t] = t < 13 ? pw[i] : 0;  // already binarised on the host: words 13..15 are padding
+    } else {
+      const uint64_t word = __ballot(px[i] >= 128 && t < 784);
+      if (lane == 0) act[0][i][wave] = word;  // waves 13..15 write zeros
+    }
   }
   lfc_load_row<16>(r1, t, w1, t1);
   __syncthreads();
@@ -1781,6 +1799,7 @@ __device__ __forceinline__ void lfc_block_handoff() {
   asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
+template <bool PACKED>
 __global__ __launch_bounds__(1024, 2) void k_lfc_block_s(const uint8_t *__restrict__ imgs, uint64_t *__restrict__ words,
                                                           int32_t *__restrict__ classes, uint64_t *__restrict__ gA, uint64_t *__restrict__ gB,
                                                           const uint32_t *__restrict__ r0, const uint32_t *__restrict__ r1,
@@ -1800,7 +1819,9 @@ __global__ __launch_bounds__(1024, 2) void k_lfc_block_s(const uint8_t *__restri
   for (int idx = tid; idx < cnt * 16; idx += 1024) {
     const int i = idx >> 4, k = idx & 15;
     uint64_t word = 0;
-    if (k < 13) {
+    if constexpr (PACKED) {  // binarised on the host (csrc/pack_inputs.h): 13 words per image, re-pitched to 16 for the scalar loads
+      if (k < 13) word = reinterpret_cast<const uint64_t *>(imgs)[(size_t)(img0 + i) * 13 + k];
+    } else if (k < 13) {
       const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(imgs + (size_t)(img0 + i) * 784 + k * 64);
       const int nq = (k == 12) ? 1 : 4;  // word 12 holds pixels 768..783 only
       for (int q = 0; q < nq; q++) {
@@ -2132,12 +2153,22 @@ hipError_t run_lfc(NetId net, const LfcLaunch &a) {
     // smallest that still fits the batch in one round of 256 blocks (profiles/r01_lfc_forms.txt).
     const int ipb = n <= 256 ? 1 : n <= 512 ? 2 : n <= 1024 ? 4 : 8;
     const dim3 g((unsigned)((n + ipb - 1) / ipb)), b(1024);
-#define BNN_FUSED(K, I)                                                                                                                   \
+#define BNN_FUSED_P(K, I, P)                                                                                                              \
   do {                                                                                                                                    \
-    if (a.t0) hipExtLaunchKernelGGL(K<I>, g, b, 0, s, a.t0, a.t1, 0, a.images, a.words, a.classes, a.rows[0], a.rows[1], a.rows[2],       \
-                                    a.rows[3], (int)n, a.number_class);                                                                   \
-    else hipLaunchKernelGGL(K<I>, g, b, 0, s, a.images, a.words, a.classes, a.rows[0], a.rows[1], a.rows[2], a.rows[3], (int)n,           \
-                            a.number_class);                                                                                              \
+    if (a.t0 && a.t_dispatch) {                                                                                                           \
+      hipExtLaunchKernelGGL((K<I, P>), g, b, 0, s, a.t0, a.t1, 0, a.images, a.words, a.classes, a.rows[0], a.rows[1], a.rows[2],          \
+                            a.rows[3], (int)n, a.number_class);                                                                           \
+    } else {                                                                                                                              \
+      if (a.t0) (void)hipEventRecord(a.t0, s);                                                                                            \
+      hipLaunchKernelGGL((K<I, P>), g, b, 0, s, a.images, a.words, a.classes, a.rows[0], a.rows[1], a.rows[2], a.rows[3], (int)n,         \
+                         a.number_class);                                                                                                 \
+      if (a.t1) (void)hipEventRecord(a.t1, s);                                                                                            \
+    }                                                                                                                                     \
+  } while (0)
+#define BNN_FUSED(K, I)                      \
+  do {                                       \
+    if (a.packed) BNN_FUSED_P(K, I, true);   \
+    else BNN_FUSED_P(K, I, false);           \
   } while (0)
     if (net == NET_LFCW1A1) {
       if (ipb == 1) BNN_FUSED(k_lfc_fused, 1);
@@ -2153,25 +2184,40 @@ hipError_t run_lfc(NetId net, const LfcLaunch &a) {
       return hipErrorInvalidValue;
     }
 #undef BNN_FUSED
+#undef BNN_FUSED_P
     return hipGetLastError();
   }
   if (net == NET_LFCW1A1 && n <= lfc_block_max() && !a.events && a.last_stage >= kLfcStages - 1) {
     // mid-size batch: two 1024-thread blocks per CU, each walking all four layers over its share of the images
     const int ipb = (int)((n + 511) / 512);
     const dim3 g((unsigned)((n + ipb - 1) / ipb)), b(1024);
-    if (a.t0) hipExtLaunchKernelGGL(k_lfc_block_s, g, b, 0, s, a.t0, a.t1, 0, a.images, a.words, a.classes, A64, B64, a.rows[0], a.rows[1],
-                                    a.rows[2], a.rows[3], (int)n, a.number_class, ipb);
-    else hipLaunchKernelGGL(k_lfc_block_s, g, b, 0, s, a.images, a.words, a.classes, A64, B64, a.rows[0], a.rows[1], a.rows[2], a.rows[3],
-                            (int)n, a.number_class, ipb);
+    auto *const kern = a.packed ? k_lfc_block_s<true> : k_lfc_block_s<false>;
+    if (a.t0 && a.t_dispatch) {
+      hipExtLaunchKernelGGL(kern, g, b, 0, s, a.t0, a.t1, 0, a.images, a.words, a.classes, A64, B64, a.rows[0], a.rows[1],
+                            a.rows[2], a.rows[3], (int)n, a.number_class, ipb);
+    } else {
+      if (a.t0) (void)hipEventRecord(a.t0, s);
+      hipLaunchKernelGGL(kern, g, b, 0, s, a.images, a.words, a.classes, A64, B64, a.rows[0], a.rows[1], a.rows[2], a.rows[3],
+                         (int)n, a.number_class, ipb);
+      if (a.t1) (void)hipEventRecord(a.t1, s);
+    }
     return hipGetLastError();
   }
   if (a.t0) (void)hipEventRecord(a.t0, s);
   BNN_MARK(a.events, 0, s);
-  if (a.last_stage >= 0) BNN_LAUNCH(k_lfc_binarize, grid_for(n * 13, 1), s, a.images, A64, (int)(n * 13));
+  // host-binarised input IS stage 0's output (13 words per image): layer 0 reads it where it lies; only the stage-output
+  // hook asking for stage 0 itself has it copied into the workspace
+  const uint64_t *L0in = A64;
+  if (a.packed) {
+    if (a.last_stage == 0) (void)hipMemcpyAsync(A64, a.images, (size_t)n * 13 * 8, hipMemcpyDeviceToDevice, s);
+    else L0in = reinterpret_cast<const uint64_t *>(a.images);
+  } else if (a.last_stage >= 0) {
+    BNN_LAUNCH(k_lfc_binarize, grid_for(n * 13, 1), s, a.images, A64, (int)(n * 13));
+  }
   BNN_MARK(a.events, 1, s);
   uint32_t *W32 = reinterpret_cast<uint32_t *>(a.words);
   if (net == NET_LFCW1A1) {
-    if (a.last_stage >= 1) BNN_STAGE((k_vec_x<13, false, 1, 1>), (k_vec_x<13, false, 1, 1, 8>), n, 32, A64, B, a.rows[0]);
+    if (a.last_stage >= 1) BNN_STAGE((k_vec_x<13, false, 1, 1>), (k_vec_x<13, false, 1, 1, 8>), n, 32, L0in, B, a.rows[0]);
     BNN_MARK(a.events, 2, s);
     if (a.last_stage >= 2) BNN_STAGE((k_vec_x<16, false, 1, 1>), (k_vec_x<16, false, 1, 1, 8>), n, 32, B64, A, a.rows[1]);
     BNN_MARK(a.events, 3, s);
@@ -2180,7 +2226,7 @@ hipError_t run_lfc(NetId net, const LfcLaunch &a) {
     if (a.last_stage >= 4) BNN_STAGE((k_vec_x<16, false, 1, 1>), (k_vec_x<16, false, 1, 1, 8>), n, 2, B64, W32, a.rows[3]);
     BNN_MARK(a.events, 5, s);
   } else if (net == NET_LFCW1A2) {
-    if (a.last_stage >= 1) BNN_STAGE((k_vec<AR_XNOR, 13, true, false, 1, 1>), (k_vec<AR_XNOR, 13, true, false, 1, 1, 8>), n, 32, A64, B, a.rows[0]);
+    if (a.last_stage >= 1) BNN_STAGE((k_vec<AR_XNOR, 13, true, false, 1, 1>), (k_vec<AR_XNOR, 13, true, false, 1, 1, 8>), n, 32, L0in, B, a.rows[0]);
     BNN_MARK(a.events, 2, s);
     if (a.last_stage >= 2) BNN_STAGE((k_vec<AR_TB, 16, true, false, 1, 1>), (k_vec<AR_TB, 16, true, false, 1, 1, 8>), n, 32, B64, A, a.rows[1]);
     BNN_MARK(a.events, 3, s);

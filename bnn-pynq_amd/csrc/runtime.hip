@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <cmath>
@@ -44,6 +45,7 @@
 #include "preprocess.h"
 #include "resample.h"
 #include "packed_params.h"
+#include "pack_inputs.h"
 #include "topology.h"
 
 #ifndef BNN_NETWORK
@@ -65,39 +67,66 @@ constexpr int kStageSlots = 4;      // HBM staging buffers of the host paths: tw
 constexpr unsigned kTimeEventFlags = hipEventReleaseToDevice;
 constexpr int kHostChunk = 32768;  // host-buffer / file path: H2D of chunk i+1 overlaps the stages of chunk i (largest chunk; LFC nets)
 constexpr int kHostChunkCnv = 16384;  // ... the CNV nets since the chunks run on two compute lanes (below)
-constexpr int kHeadChunk = 2048;   // ... the first chunk: what the stages wait for before anything runs
+constexpr int kHeadChunk = 512;    // ... the first chunk: what the stages wait for before anything runs
+constexpr int kFastGrowthBelow = 4096;  // ... chunks double up to here, then grow by half
+// Pinned, device-mapped I/O block (ensure_io): small calls cross the PCIe link by the kernels' own loads and stores --
+// no hipMemcpy, no staging, one wait.  Input area: a single CIFAR record (body 16-byte aligned) or up to kDirectMaxLfc
+// host-binarised MNIST images; result area: classes / raw words of up to kMappedResMax images, scores of kMappedScoresMax.
+constexpr int kDirectMaxLfc = 1024;   // images: an LFC call up to here is binarised by the calling thread and read in place
+constexpr int kDirectMaxCnv = 1;      // a single CIFAR image (classify_image / the webcam loop: inference(path) per frame)
+constexpr int kMappedResMax = 32768, kMappedScoresMax = 256;
+constexpr size_t kIoInBytes = 256u << 10;
+constexpr size_t kIoClassesOff = kIoInBytes, kIoWordsOff = kIoClassesOff + (size_t)kMappedResMax * 4,
+                 kIoScoresOff = kIoWordsOff + (size_t)kMappedResMax * 8, kIoBytes = kIoScoresOff + (size_t)kMappedScoresMax * 128;
+static_assert((size_t)kDirectMaxLfc * kLfcWords * 8 <= kIoInBytes && 16 + 3073 <= kIoInBytes, "input area too small");
 
 // Chunk boundaries of a host-buffer / file call: base[c] .. base[c+1] are the images of chunk c.
-// The pipeline is copy | stages, double buffered.  With equal chunks the first copy (32 768 CIFAR records =
-// 100 MB: ~3 ms of pread + H2D) runs with the GPU idle, so the chunks ramp up -- by a factor that keeps the NEXT
-// chunk's transfer about as long as THIS chunk's stages, or the stages starve at every step of the ramp (measured with
-// a device timeline, profiles/r03_host_path_timelines.txt: doubling left 0.3-0.8 ms holes).  Both sources now arrive
+// The pipeline is copy | stages, double buffered per compute lane.  With equal chunks the first copy (32 768 CIFAR records
+// = 100 MB: ~3 ms of pread + H2D) runs with the GPU idle, so the chunks ramp up -- by a factor that keeps the NEXT chunk's
+// transfer about as long as THIS chunk's stages, or the stages starve at every step of the ramp (measured with a device
+// timeline, profiles/r03_host_path_timelines.txt: doubling 2 048 -> 32 768 left 0.3-0.8 ms holes).  Both sources arrive
 // faster than the stages consume them (a buffer in host memory at 54 GB/s = 17.6 M CIFAR images/s, a file through the
-// pinned ring and two DMA queues at ~46 GB/s = 15 M/s, against 12.5 M/s of stages), so a call is compute-bound: what ends
-// it is the last chunk's stages whatever their size -- no ramp down -- and small chunks cost stage efficiency (2 048 images
-// run at 9.7 M/s, 32 768 at 12.1): x1.5 per step from 2 048 (buffer) / 4 096 (file) images up to 32 768
-// (profiles/r03_chunk_plan_sweep.txt, r03_file_path_two_queues_plan_sweep.txt).  Since the chunks alternate over two
-// compute lanes ("Two compute lanes" below) one chunk's launch gaps and tails are filled by the other's kernels, small
-// chunks cost less and the CNV plan stops growing at 16 384: 131 072 images from a buffer 11.36 -> 11.02 ms, 1 048 576
-// 87.2 -> 84.5 ms, from a file 88.4 -> 86.3 ms (profiles/r03_two_lanes_plan_sweep.txt).
-// BNN_MI355X_CHUNKS=head:tail:max[:growth%] overrides the sizes (0 = no ramp at that end; tuning / A-B runs).
-std::vector<int> plan_chunks(int n, bool single, bool from_file) {
+// pinned ring and two DMA queues at ~46 GB/s = 15 M/s, against 12.5 M/s of stages at full-size chunks), so a call is
+// compute-bound: what ends it is the last chunk's stages whatever their size -- no ramp down.  Round 4, on the reference's
+// own call size (a 10 000-record test-set file: 30 MB, 0.94 ms of stages): the first chunk's transfer is the one thing
+// nothing hides, and small chunks run their stages at 7-10 M images/s -- half the link's rate -- so the head of the plan is
+// 512 images and DOUBLES up to 4 096 (the next transfer still fits behind the current stages), then grows by half up to
+// 16 384 (CNV; the LFC nets: four times these sizes in images, an MNIST image is a quarter of a CIFAR one):
+// 10 000 records from a file 1.59 -> 1.25 ms, from a buffer 1.16 -> 1.14 ms on the plan alone
+// (profiles/r04_small_call_plan_sweep.txt; r03_chunk_plan_sweep.txt and r03_two_lanes_plan_sweep.txt for the large calls).
+// The chunks alternate over two compute lanes ("Two compute lanes" below): one chunk's launch gaps and tails are filled by
+// the other's kernels.
+// BNN_MI355X_CHUNKS=head:tail:max[:growth%] overrides the sizes (0 = no ramp at that end; a growth given here applies
+// to every step; tuning / A-B runs).
+std::vector<int> plan_chunks(int n, bool single, bool /*from_file*/) {
   // (sizes are tuned in bytes on CIFAR records: an MNIST image is a quarter of one)
-  const int scale = net_spec(BNN_NETWORK).is_cnv ? 1 : 4;
-  int head = (from_file ? 2 : 1) * kHeadChunk * scale, tail = 0, big = net_spec(BNN_NETWORK).is_cnv ? kHostChunkCnv : kHostChunk, growth = 150;
+  // The LFC nets' host paths ship binarised words (104 bytes per image, "binarizeAndPack on the host" below): what a chunk
+  // waits for is its share of the binarising cores' work, not the link, and the one-launch kernel is at its best on large
+  // chunks -- 8 192 images first, doubling (131 072 images: 102 M images/s with 2 048 first, 115-119 M with 8 192;
+  // 10 000 images as ONE chunk 62 M/s against 53 M/s in three; profiles/r04_small_call_plan_sweep.txt).
+  const bool cnv = net_spec(BNN_NETWORK).is_cnv;
+  const int scale = cnv ? 1 : 4;
+  // ... and a CNV call below 32 768 images ramps DOWN as well: at that size the bytes arrive about as fast as small chunks'
+  // stages consume them, and what follows the last byte is the last chunk's stages (10 000 images from a buffer 1.146 ->
+  // 1.094 ms, from a file 1.33 -> 1.275; 131 072 images lose 3 % to the small chunks at the end and keep the one-sided ramp)
+  int head = cnv ? kHeadChunk : 8192, tail = (cnv && n < 32768) ? kHeadChunk : 0, big = cnv ? kHostChunkCnv : kHostChunk, growth = cnv ? 0 : 200;
   if (const char *e = std::getenv("BNN_MI355X_CHUNKS")) {
-    int h = 0, t = 0, b = 0, g = growth;
+    int h = 0, t = 0, b = 0, g = 150;
     const int got = std::sscanf(e, "%d:%d:%d:%d", &h, &t, &b, &g);
-    if (got >= 3 && b >= 256 && b <= kMaxChunk && h >= 0 && t >= 0 && g > 100 && g <= 400) { head = h; tail = t; big = b; growth = g; }
+    // (head and tail are clamped to `max`: no field of the override can ask for a chunk above the activation workspace)
+    if (got >= 3 && b >= 256 && b <= kMaxChunk && h >= 0 && t >= 0 && g > 100 && g <= 400) { head = h < b ? h : b; tail = t < b ? t : b; big = b; growth = g; }
   }
   std::vector<int> front, back;
   int rem = n;
-  if (single || n <= 2 * head) {  // nothing worth overlapping
+  // nothing worth overlapping: one chunk -- but never one above the largest chunk of the plan (`single`, the stage-output
+  // hook, is limited to kHostChunk images by its caller)
+  if ((single && n <= kMaxChunk) || (n <= 2LL * head && n <= big)) {
     front.push_back(n);
     rem = 0;
   }
   auto grow = [&](int s) {
-    const long long g = ((long long)s * growth / 100 + 255) & ~255LL;  // whole 256-image blocks
+    const int pct = growth ? growth : (s < kFastGrowthBelow * scale ? 200 : 150);
+    const long long g = ((long long)s * pct / 100 + 255) & ~255LL;  // whole 256-image blocks
     return (int)(g < big ? g : big);
   };
   int sf = head > 0 ? head : big, sb = tail > 0 ? tail : big;
@@ -115,7 +144,8 @@ std::vector<int> plan_chunks(int n, bool single, bool from_file) {
     }
   }
   // a small remainder joins the chunk in front of it (a chunk of a few hundred images costs nine launches all the same)
-  if (back.empty() && front.size() >= 2 && front.back() * 2 < front[front.size() - 2] && front.back() + front[front.size() - 2] <= big) {
+  // (with a ramp at both ends the remainder is the chunk in the middle)
+  if (front.size() >= 2 && front.back() * 2 < front[front.size() - 2] && front.back() + front[front.size() - 2] <= big) {
     front[front.size() - 2] += front.back();
     front.pop_back();
   }
@@ -167,6 +197,15 @@ struct Runtime {
   int32_t *d_classes = nullptr;
   uint64_t *d_words = nullptr;
   hipStream_t stream = nullptr, copy_stream = nullptr;
+  // pinned host memory the GPU addresses directly (kIo* above): h_io as the CPU sees it, d_io as the kernels do
+  uint8_t *h_io = nullptr, *d_io = nullptr;
+  hipEvent_t io_t0 = nullptr, io_t1 = nullptr;  // device time of a direct call (system-scope release: the host reads what the kernels wrote)
+  std::vector<uint8_t> h_scratch;               // direct LFC calls from a file: the pixels on their way to the binariser
+  // results of calls above kMappedResMax images: ONE D2H at the end of the call into pinned memory (a pageable destination
+  // would be staged by the runtime), handed to the caller / decoded from there
+  int32_t *h_classes = nullptr;
+  uint64_t *h_words = nullptr;
+  size_t h_classes_cap = 0, h_words_cap = 0;
   // The activation workspace (buf0/buf1, d_words) is shared by every call.  Host-path calls drain r.stream
   // before they return; bnn_mi355x_inference_device leaves work in flight on the CALLER's stream, so it marks
   // the end of that work with ws_event and the next call on any other stream waits for it first.
@@ -211,6 +250,39 @@ int fail(const std::string &msg) {
   return -1;
 }
 
+// BNN_MI355X_TRACE=1: host-side time stamps of a host-data call (microseconds since its start) on stderr -- where a call's
+// wall time goes that no device timeline shows (tools/small_call_sweep.py prints them next to the rates)
+struct CallTrace {
+  const bool on = std::getenv("BNN_MI355X_TRACE") != nullptr;
+  std::chrono::steady_clock::time_point t0;
+  std::vector<std::pair<std::string, double>> marks;
+  double now() const { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
+  void start() {
+    if (!on) return;
+    t0 = std::chrono::steady_clock::now();
+    marks.clear();
+  }
+  void mark(const char *what, int k = -1) {
+    if (!on) return;
+    marks.emplace_back(k < 0 ? std::string(what) : std::string(what) + "[" + std::to_string(k) + "]", now());
+  }
+  void dump(const char *title) {
+    if (!on) return;
+    std::string line = std::string("bnn-mi355x trace ") + title + ":";
+    char buf[64];
+    for (auto &m : marks) {
+      std::snprintf(buf, sizeof buf, " %s=%.0f", m.first.c_str(), m.second);
+      line += buf;
+    }
+    std::fprintf(stderr, "%s\n", line.c_str());
+    marks.clear();
+  }
+};
+CallTrace &trace() {
+  static CallTrace t;
+  return t;
+}
+
 #define HIP_OK(expr)                                                                     \
   do {                                                                                   \
     hipError_t e_ = (expr);                                                              \
@@ -242,6 +314,7 @@ int bind_device() {
 // On a failing exit nothing may still be queued that reads the caller's buffers, the host chunks or the patch
 // images, or that writes the caller's result arrays: the caller is free to release them as soon as it sees
 // the error.  (A successful exit has waited for its streams anyway.)
+void drain_feeder();  // (the pinned ring's second DMA queue, below)
 struct DrainOnFailure {
   bool armed = true;
   void ok() { armed = false; }
@@ -251,6 +324,7 @@ struct DrainOnFailure {
     if (r.stream) (void)hipStreamSynchronize(r.stream);
     if (r.stream2) (void)hipStreamSynchronize(r.stream2);
     if (r.copy_stream) (void)hipStreamSynchronize(r.copy_stream);
+    drain_feeder();  // DMAs still reading the pinned ring: the next job's workers would refill it under them
   }
 };
 
@@ -286,9 +360,18 @@ int upload_blob() {
 
 void free_workspace() {
   Runtime &r = rt();
-  if (r.cap == 0 && r.cap2 == 0 && r.stage_cap == 0 && r.res_cap == 0 && !r.d_pp_src && !r.d_pp_rec && !r.file_cap && !r.all_cap && !r.d_rec_cap) return;
+  if (r.cap == 0 && r.cap2 == 0 && r.stage_cap == 0 && r.res_cap == 0 && !r.d_pp_src && !r.d_pp_rec && !r.file_cap && !r.all_cap && !r.d_rec_cap && !r.h_io &&
+      !r.h_classes && !r.h_words)
+    return;
   if (r.device >= 0) (void)hipSetDevice(r.device);
   (void)hipDeviceSynchronize();
+  if (r.h_io) (void)hipHostFree(r.h_io);
+  r.h_io = r.d_io = nullptr;
+  if (r.h_classes) (void)hipHostFree(r.h_classes);
+  if (r.h_words) (void)hipHostFree(r.h_words);
+  r.h_classes = nullptr; r.h_words = nullptr;
+  r.h_classes_cap = r.h_words_cap = 0;
+  r.h_scratch = std::vector<uint8_t>();
   (void)hipFree(r.buf0); (void)hipFree(r.buf1);
   for (auto &b : r.d_images) { (void)hipFree(b); b = nullptr; }
   (void)hipFree(r.d_scores); (void)hipFree(r.d_classes); (void)hipFree(r.d_words);
@@ -325,6 +408,22 @@ int grow(T *&ptr, size_t &cap, size_t need) {
   cap = 0;
   const size_t n = need + need / 4 + 256;
   HIP_OK(hipMalloc(reinterpret_cast<void **>(&ptr), n * sizeof(T)));
+  cap = n;
+  return 0;
+}
+
+// grow-only pinned host buffer (contents are not preserved)
+template <typename T>
+int grow_pinned(T *&ptr, size_t &cap, size_t need) {
+  if (need <= cap) return 0;
+  if (ptr) {
+    HIP_OK(hipStreamSynchronize(rt().stream));
+    (void)hipHostFree(ptr);
+  }
+  ptr = nullptr;
+  cap = 0;
+  const size_t n = need + need / 4 + 256;
+  HIP_OK(hipHostMalloc(reinterpret_cast<void **>(&ptr), n * sizeof(T), hipHostMallocDefault));
   cap = n;
   return 0;
 }
@@ -449,6 +548,49 @@ int reserve_host(int chunk, size_t n_total, int slots = 2) {
   return 0;
 }
 
+// the pinned, device-mapped I/O block (kIo*); once per load (warm_up) or at first use
+int ensure_io() {
+  Runtime &r = rt();
+  if (r.h_io) return 0;
+  if (bind_device()) return -1;
+  void *h = nullptr, *d = nullptr;
+  HIP_OK(hipHostMalloc(&h, kIoBytes, hipHostMallocMapped));
+  if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess || !d) {
+    (void)hipHostFree(h);
+    return fail("pinned I/O block: no device address for host memory");
+  }
+  std::memset(h, 0, kIoBytes);
+  r.h_io = static_cast<uint8_t *>(h);
+  r.d_io = static_cast<uint8_t *>(d);
+  if (!r.io_t0) {
+    HIP_OK(hipEventCreate(&r.io_t0));
+    HIP_OK(hipEventCreate(&r.io_t1));
+  }
+  return 0;
+}
+
+// mapped result slots of a call of n images (null: that result goes through HBM and a copy)
+struct ResultSlots {
+  int32_t *h_classes = nullptr, *d_classes = nullptr;
+  uint64_t *h_words = nullptr, *d_words = nullptr;
+  int16_t *h_scores = nullptr, *d_scores = nullptr;
+};
+ResultSlots mapped_results(int n, bool scores) {
+  Runtime &r = rt();
+  ResultSlots m;
+  static const bool off = std::getenv("BNN_MI355X_NO_MAPPED_RESULTS") != nullptr;  // A/B
+  if (off || n > kMappedResMax || (scores && n > kMappedScoresMax) || ensure_io()) return m;
+  m.h_classes = reinterpret_cast<int32_t *>(r.h_io + kIoClassesOff);
+  m.d_classes = reinterpret_cast<int32_t *>(r.d_io + kIoClassesOff);
+  m.h_words = reinterpret_cast<uint64_t *>(r.h_io + kIoWordsOff);
+  m.d_words = reinterpret_cast<uint64_t *>(r.d_io + kIoWordsOff);
+  if (scores) {
+    m.h_scores = reinterpret_cast<int16_t *>(r.h_io + kIoScoresOff);
+    m.d_scores = reinterpret_cast<int16_t *>(r.d_io + kIoScoresOff);
+  }
+  return m;
+}
+
 // An earlier device-pointer call on another stream may still own the activation workspaces: work about to be queued on
 // `s` waits for its end first.
 int settle_handover(hipStream_t s) {
@@ -482,11 +624,13 @@ int settle_handover(hipStream_t s) {
 // enqueue one chunk (n <= cap) whose images are already in HBM
 // t0 / t1 (optional): this chunk's device time is t0 -> t1 (kernels.h)
 int enqueue(const uint8_t *d_imgs, int n, int ncls, int32_t *d_classes, int16_t *d_scores, uint64_t *d_words,
-            hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr, int lane = 0) {
+            hipStream_t s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr, int lane = 0, bool t_dispatch = false, bool packed = false) {
   Runtime &r = rt();
   hipError_t e;
   hipEvent_t *evs = nullptr;
   void *const ws0 = lane ? r.buf0b : r.buf0, *const ws1 = lane ? r.buf1b : r.buf1;
+  // (the stages index the workspace by image: a chunk above its capacity would write past it on the device)
+  if (n > (lane ? r.cap2 : r.cap)) return fail("internal: a chunk of " + std::to_string(n) + " images exceeds the activation workspace");
   if (settle_handover(s)) return -1;
   if (r.profiling) {
     const int need = (r.spec.is_cnv ? kCnvStages : kLfcStages) + 1;
@@ -511,12 +655,12 @@ int enqueue(const uint8_t *d_imgs, int n, int ncls, int32_t *d_classes, int16_t 
     e = run_cnv(r.spec.id, a);
   } else {
     LfcLaunch a{};
-    a.images = d_imgs; a.n = n; a.buf0 = ws0; a.buf1 = ws1;
+    a.images = d_imgs; a.packed = packed; a.n = n; a.buf0 = ws0; a.buf1 = ws1;
     for (int l = 0; l < 4; l++) a.rows[l] = r.rows[l];
     a.words = d_words;
     a.classes = d_classes; a.number_class = ncls; a.stream = s; a.events = evs;
     a.last_stage = r.debug_last_stage >= 0 ? r.debug_last_stage : kLfcStages - 1;
-    a.t0 = t0; a.t1 = t1;
+    a.t0 = t0; a.t1 = t1; a.t_dispatch = t_dispatch;
     e = run_lfc(r.spec.id, a);
   }
   if (e != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(e));
@@ -535,7 +679,7 @@ bool ready() {
 // kFeederMinBytes and more, worker threads fill 4 MB pinned pieces -- memcpy from the caller's buffer, or pread()
 // straight from the page cache -- and the calling thread, the only one that talks to HIP, sends each piece with an
 // asynchronous DMA as soon as it is full: one CPU copy per byte, spread over the cores this process may use.
-constexpr size_t kFeederMinBytes = 24u << 20;
+constexpr size_t kFeederMinBytes = 2u << 20;  // (24 MB until round 4: with the small first pieces and the caller's own first piece a 5 000-record file takes 0.80 ms through the ring, 1.03 ms through a pageable chunk)
 int usable_cpus() {
   int n = 0;
   cpu_set_t set;
@@ -564,9 +708,24 @@ __attribute__((target("clflushopt"))) void flush_lines(const uint8_t *p, size_t 
 
 struct Feeder {
   static constexpr int kSlots = 12;
+  static constexpr int kMaxWorkers = 14;
   size_t kSlotBytes = 4u << 20;  // BNN_MI355X_FEEDER_PIECE_MB overrides (tuning): alone, 4 MB pieces move at 49 GB/s, 8 MB at 52, 16 MB at 54
                                  // (profiles/r03_h2d_probe.txt); behind the readers 2-4 MB pieces gave the shortest calls
-  struct Piece { int chunk; size_t off_in_chunk, src_off, bytes; bool last_of_chunk; };
+  // A PIECE is what one worker fills in one go (256-512 KB of source: a pread of that size takes 20-40 us, so the pieces of
+  // a group are read side by side); a GROUP is what goes to HBM with one DMA: the pieces that share ring slot
+  // (group % kSlots), up to kSlotBytes -- DMAs of 1-4 MB move at the link's rate, smaller ones cost ~10 us each whatever
+  // their size (round 4's first form had piece = DMA: 4 MB pieces took one reader 0.3 ms each and the last bytes of a
+  // 30 MB file arrived at 1.16 ms, 256 KB pieces moved at a third of the link's rate;
+  // profiles/r04_timeline_cnvW1A1_10000_file_*.txt).  RAW job (CNV records, images as they are): source bytes are copied.
+  // PACKED job (LFC: binarizeAndPack on the host, csrc/pack_inputs.h): `bytes` = whole 784-byte images, their 13-word
+  // forms are what lands in the ring, and a chunk is one group (104 bytes per image: 32 768 images are 3.4 MB).
+  struct Piece {
+    int chunk, group;
+    size_t ring_off;   // where in the group's ring slot this piece's output goes
+    size_t src_off, bytes;
+    bool last_of_group, last_of_chunk;
+    size_t group_dst_off, group_bytes;  // (on the last piece of a group) the group's place in the chunk's HBM buffer and its size
+  };
   uint8_t *ring = nullptr;  // kSlots x kSlotBytes, pinned
   bool ready = false;       // init() went through: ring, events, streams and workers exist
   hipEvent_t sent[kSlots] = {};
@@ -578,6 +737,7 @@ struct Feeder {
   hipEvent_t aux_done = nullptr;
   bool flush = false;
   std::vector<std::thread> workers;
+  int raw_workers = 1;  // a RAW job keeps the first raw_workers threads busy (more readers slow the DMA down), a PACKED job all of them
   std::mutex mu;
   std::condition_variable cv_job, cv_done;
   bool quit = false;
@@ -586,26 +746,73 @@ struct Feeder {
   const std::vector<Piece> *pieces = nullptr;
   const uint8_t *mem = nullptr;  // source: host memory ...
   int fd = -1;                   // ... or a file
-  std::atomic<size_t> next{0}, released{0};
+  bool packed = false;
+  int job_workers = 0;
+  std::atomic<size_t> next{0}, released{0};  // released: groups whose DMA is done (their ring slot may be refilled)
   std::unique_ptr<std::atomic<uint8_t>[]> filled;  // per piece: 0 not yet, 1 filled, 2 failed
   size_t filled_cap = 0;
   std::atomic<bool> abort{false};
   int active = 0;  // workers that have not yet left the current job (under mu)
+  // BNN_MI355X_TRACE: per worker, microseconds from begin() to its first claim, microseconds spent filling, pieces filled
+  struct Stat { double first = -1, busy = 0; int pieces = 0; };
+  Stat stats[kMaxWorkers + 1];
+  std::chrono::steady_clock::time_point job_t0;
 
-  bool fill(const Piece &pc, uint8_t *dst) const {
-    if (mem) { std::memcpy(dst, mem + pc.src_off, pc.bytes); return true; }
+  uint8_t *ring_at(const Piece &pc) const { return ring + (size_t)(pc.group % kSlots) * kSlotBytes + pc.ring_off; }
+  bool read_all(uint8_t *dst, size_t bytes, size_t off) const {
     size_t done = 0;
-    while (done < pc.bytes) {
-      const ssize_t got = ::pread(fd, dst + done, pc.bytes - done, (off_t)(pc.src_off + done));
+    while (done < bytes) {
+      const ssize_t got = ::pread(fd, dst + done, bytes - done, (off_t)(off + done));
       if (got <= 0) return false;
       done += (size_t)got;
     }
+    return true;
+  }
+  bool fill(const Piece &pc, uint8_t *dst) const {
+    if (packed) {
+      const size_t images = pc.bytes / kLfcPixels;
+      if (mem) { binarize_pack(mem + pc.src_off, images, reinterpret_cast<uint64_t *>(dst)); return true; }
+      // from a file: the pixels pass through a cache-sized scratch block on their way to the binariser
+      constexpr size_t kBlock = 80;  // images: 62 720 bytes
+      uint8_t scratch[kBlock * kLfcPixels];
+      for (size_t i = 0; i < images; i += kBlock) {
+        const size_t m = images - i < kBlock ? images - i : kBlock;
+        if (!read_all(scratch, m * kLfcPixels, pc.src_off + i * kLfcPixels)) return false;
+        binarize_pack(scratch, m, reinterpret_cast<uint64_t *>(dst) + i * kLfcWords);
+      }
+      return true;
+    }
+    if (mem) { std::memcpy(dst, mem + pc.src_off, pc.bytes); return true; }
+    if (!read_all(dst, pc.bytes, pc.src_off)) return false;
 #if defined(__x86_64__)
     if (flush) flush_lines(dst, pc.bytes);
 #endif
     return true;
   }
-  void worker() {
+  // claim the next piece and fill it; false when none is left.  (Also called once by the thread that started the job:
+  // the workers need some tens of microseconds to wake up, and the first piece is what everything waits for.)
+  bool work_one(int who = kMaxWorkers) {
+    const size_t np = pieces->size();
+    const size_t p = next.fetch_add(1, std::memory_order_relaxed);
+    if (p >= np) return false;
+    const Piece &pc = (*pieces)[p];
+    // (its ring slot is free once the DMA of the group that had it before is done: `released` counts finished DMAs)
+    while (!abort.load(std::memory_order_relaxed) && (size_t)pc.group >= released.load(std::memory_order_acquire) + kSlots) std::this_thread::yield();
+    const bool tr = trace().on;
+    std::chrono::steady_clock::time_point a;
+    if (tr) {
+      a = std::chrono::steady_clock::now();
+      if (stats[who].first < 0) stats[who].first = std::chrono::duration<double, std::micro>(a - job_t0).count();
+    }
+    const bool ok = !abort.load(std::memory_order_relaxed) && fill(pc, ring_at(pc));
+    if (tr) {
+      stats[who].busy += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - a).count();
+      stats[who].pieces++;
+    }
+    filled[p].store(ok ? 1 : 2, std::memory_order_release);
+    return true;
+  }
+  void worker(int index) {
     uint64_t seen = 0;
     for (;;) {
       {
@@ -613,15 +820,9 @@ struct Feeder {
         cv_job.wait(lk, [&] { return quit || job_id != seen; });
         if (quit) return;
         seen = job_id;
+        if (index >= job_workers) continue;  // not needed for this job (and not counted in `active`)
       }
-      const size_t np = pieces->size();
-      for (;;) {
-        const size_t p = next.fetch_add(1, std::memory_order_relaxed);
-        if (p >= np) break;
-        while (!abort.load(std::memory_order_relaxed) && p >= released.load(std::memory_order_acquire) + kSlots) std::this_thread::yield();
-        const bool ok = !abort.load(std::memory_order_relaxed) && fill((*pieces)[p], ring + (p % kSlots) * kSlotBytes);
-        filled[p].store(ok ? 1 : 2, std::memory_order_release);
-      }
+      while (work_one(index)) {}
       std::lock_guard<std::mutex> lk(mu);
       if (--active == 0) cv_done.notify_all();
     }
@@ -645,35 +846,60 @@ struct Feeder {
 #if defined(__x86_64__)
     flush = (ef ? std::atoi(ef) != 0 : false) && __builtin_cpu_supports("clflushopt");
 #endif
-    // Readers: 4 pread() threads already move 45 GB/s out of the page cache (8: 74 GB/s), more than the link takes;
-    // beyond ~6 the DMA, which reads the lines they have just written, slows down more than they speed up
+    // Readers of a RAW job: 4 pread() threads already move 45 GB/s out of the page cache (8: 74 GB/s), more than the link
+    // takes; beyond ~6 the DMA, which reads the lines they have just written, slows down more than they speed up
     // (profiles/r03_file_path_sweep.txt: 2 threads 20.4 ms per 131 072-record file, 4: 12.9-14.7, 6: 14.1, 14: 14.2).
-    int nt = usable_cpus() - 2;  // leave a core to the calling thread and one to the driver's
-    nt = nt > 6 ? 6 : nt;
-    if (const char *e = std::getenv("BNN_MI355X_FEEDER_THREADS")) nt = std::atoi(e);
-    nt = nt < 1 ? 1 : (nt > 14 ? 14 : nt);
-    for (int i = 0; i < nt; i++) workers.emplace_back([this] { worker(); });
+    // A PACKED job is the other way round -- 7.5 source bytes per byte that crosses the link, the binarising cores are the
+    // bound -- and takes every core this process may use but two (one for the calling thread, one for the driver's).
+    const int avail = usable_cpus() - 2;
+    int nr = avail > 6 ? 6 : avail, nt = avail > kMaxWorkers ? kMaxWorkers : avail;
+    if (const char *e = std::getenv("BNN_MI355X_FEEDER_THREADS")) nr = std::atoi(e);
+    if (const char *e = std::getenv("BNN_MI355X_PACK_THREADS")) nt = std::atoi(e);
+    nr = nr < 1 ? 1 : (nr > kMaxWorkers ? kMaxWorkers : nr);
+    nt = nt < nr ? nr : (nt > kMaxWorkers ? kMaxWorkers : nt);
+    raw_workers = nr;
+    for (int i = 0; i < nt; i++) workers.emplace_back([this, i] { worker(i); });
     ready = true;
     return 0;
   }
-  void begin(const std::vector<Piece> &pcs, const uint8_t *m, int f) {
+  void begin(const std::vector<Piece> &pcs, const uint8_t *m, int f, bool pack) {
     if (pcs.size() > filled_cap) {
       filled.reset(new std::atomic<uint8_t>[pcs.size()]);
       filled_cap = pcs.size();
     }
     for (size_t i = 0; i < pcs.size(); i++) filled[i].store(0, std::memory_order_relaxed);
     next = 0; released = 0; abort = false;
-    std::lock_guard<std::mutex> lk(mu);
-    pieces = &pcs; mem = m; fd = f;
-    active = (int)workers.size();
-    job_id++;
-    cv_job.notify_all();
+    if (trace().on) {
+      for (auto &st : stats) st = Stat{};
+      job_t0 = std::chrono::steady_clock::now();
+    }
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      pieces = &pcs; mem = m; fd = f; packed = pack;
+      const int want = pack ? (int)workers.size() : raw_workers;
+      // (no more threads than pieces: a thread woken for nothing still has to be waited for at the end)
+      job_workers = (size_t)want < pcs.size() ? want : (int)pcs.size();
+      active = job_workers;
+      job_id++;
+      cv_job.notify_all();
+    }
+    (void)work_one();  // the first piece by this thread, while the workers wake up
   }
   // every worker has left the job: its description may go out of scope
   void end() {
     abort = true;  // (a no-op after a complete run: nothing is left to claim)
     std::unique_lock<std::mutex> lk(mu);
     cv_done.wait(lk, [&] { return active == 0; });
+    if (trace().on) {
+      std::string line = "bnn-mi355x trace feeder (worker: first claim us / busy us / pieces; last = the calling thread):";
+      char buf[64];
+      for (int i = 0; i <= kMaxWorkers; i++) {
+        if (stats[i].pieces == 0) continue;
+        std::snprintf(buf, sizeof buf, " %d:%.0f/%.0f/%d", i, stats[i].first, stats[i].busy, stats[i].pieces);
+        line += buf;
+      }
+      std::fprintf(stderr, "%s\n", line.c_str());
+    }
   }
 };
 // One per process, never destroyed: its threads sleep on a condition variable between jobs and end with the process
@@ -682,20 +908,32 @@ Feeder &feeder() {
   static Feeder *f = new Feeder;
   return *f;
 }
+void drain_feeder() {
+  Feeder &f = feeder();
+  if (f.aux) (void)hipStreamSynchronize(f.aux);
+}
+// calls of this many source bytes and more go through the ring (BNN_MI355X_FEEDER_MIN_MB overrides; tuning)
 bool use_feeder(size_t bytes) {
   static const bool off = std::getenv("BNN_MI355X_NO_FEEDER") != nullptr;
-  return !off && bytes >= kFeederMinBytes;
+  static const size_t min_bytes = [] {
+    const char *e = std::getenv("BNN_MI355X_FEEDER_MIN_MB");
+    return e ? (size_t)std::atoi(e) << 20 : kFeederMinBytes;
+  }();
+  return !off && bytes >= min_bytes;
 }
 
-// n images from host memory (fd < 0) or from an open file, cut by `plan`, through the pinned ring into the two HBM
-// chunk buffers; consume(c, base, m, slot) enqueues chunk c's stages on its lane's stream (lane_stream) once its bytes
-// (label bytes stripped: rec > isz) are in r.d_images[slot] and that stream has been made to wait for them.
+// n images from host memory (fd < 0) or from an open file, cut by `plan`, through the pinned ring into the HBM chunk
+// buffers; consume(c, base, m, slot) enqueues chunk c's stages on its lane's stream (lane_stream) once its bytes
+// (RAW: label bytes stripped, rec > isz; PACKED: 13 words per image) are in r.d_images[slot] and that stream has been
+// made to wait for them.
 template <typename Consume>
-int feed_chunks(const uint8_t *mem, int fd, size_t first, size_t rec, size_t skip, const std::vector<int> &plan, int lanes, Consume consume) {
+int feed_chunks(const uint8_t *mem, int fd, size_t first, size_t rec, size_t skip, const std::vector<int> &plan, int lanes, bool packed, Consume consume) {
   Runtime &r = rt();
   Feeder &F = feeder();
   if (F.init()) return fail("pinned staging ring: allocation failed");
   const int nchunks = (int)plan.size() - 1, nslots = slots_for(lanes);
+  if (packed && (skip || rec != (size_t)kLfcPixels || (size_t)largest_chunk(plan) * kLfcWords * 8 > F.kSlotBytes))
+    return fail("internal: packed feed of a chunk that does not fit a ring slot");
   if (skip) {  // records go to HBM as they lie on disk; k_strip_records drops the label bytes
     size_t need = (size_t)largest_chunk(plan) * rec + 256;
     if (need > r.d_rec_cap || nslots > r.rec_slots) {
@@ -713,24 +951,52 @@ int feed_chunks(const uint8_t *mem, int fd, size_t first, size_t rec, size_t ski
       r.rec_slots = want;
     }
   }
+  // Groups (DMAs) start small and double -- the first one is what everything else waits for --, the pieces inside them are
+  // small throughout; the first chunk is one group in the smallest pieces, so that all workers share it.
   std::vector<Feeder::Piece> pieces;
+  const size_t unit = packed ? (size_t)kLfcPixels : 1;                       // source bytes per ring byte unit
+  const size_t piece0 = packed ? 256 * unit : (256u << 10), piece1 = packed ? 1024 * unit : (512u << 10);
+  size_t group_want = 1u << 20;                                             // RAW: 1, 2, 4 MB ...; PACKED: a chunk is a group
+  int ngroups = 0;
   for (int c = 0; c < nchunks; c++) {
     const size_t bytes = (size_t)(plan[c + 1] - plan[c]) * rec, src0 = first + (size_t)plan[c] * rec;
-    for (size_t o = 0; o < bytes; o += F.kSlotBytes) {
-      const size_t b = bytes - o < F.kSlotBytes ? bytes - o : F.kSlotBytes;
-      pieces.push_back({c, o, src0 + o, b, o + b == bytes});
+    for (size_t g0 = 0; g0 < bytes;) {
+      size_t gb = bytes - g0;
+      if (!packed) {
+        const size_t cap = c == 0 ? F.kSlotBytes : group_want;
+        if (gb > cap) gb = cap;
+        if (bytes - g0 - gb < gb / 4 && bytes - g0 <= F.kSlotBytes) gb = bytes - g0;  // (no crumb of a group at the end of a chunk)
+        if (c > 0) group_want = group_want * 2 < F.kSlotBytes ? group_want * 2 : F.kSlotBytes;
+      }
+      const size_t psz = c == 0 ? piece0 : piece1;
+      for (size_t o = 0; o < gb;) {
+        const size_t b = gb - o < psz ? gb - o : psz;
+        Feeder::Piece pc{};
+        pc.chunk = c; pc.group = ngroups;
+        pc.ring_off = packed ? o / kLfcPixels * kLfcWords * 8 : o;
+        pc.src_off = src0 + g0 + o; pc.bytes = b;
+        pc.last_of_group = o + b == gb;
+        pc.last_of_chunk = pc.last_of_group && g0 + gb == bytes;
+        pc.group_dst_off = packed ? g0 / kLfcPixels * kLfcWords * 8 : g0;
+        pc.group_bytes = packed ? gb / kLfcPixels * kLfcWords * 8 : gb;
+        pieces.push_back(pc);
+        o += b;
+      }
+      g0 += gb;
+      ngroups++;
     }
   }
-  F.begin(pieces, mem, fd);
+  F.begin(pieces, mem, fd, packed);
   struct End {
     Feeder &f;
     ~End() { f.end(); }
   } end_guard{F};
-  size_t issued = 0, released = 0;
-  auto release_done = [&]() {  // pieces whose DMA has finished: their ring slots may be refilled
+  size_t issued = 0, released = 0;  // in groups
+  auto release_done = [&]() {  // DMAs that have finished: their ring slots may be refilled
     while (released < issued && hipEventQuery(F.sent[released % Feeder::kSlots]) == hipSuccess) released++;
     F.released.store(released, std::memory_order_release);
   };
+  bool chunk_open = false;  // a group of the current chunk has been sent already
   for (size_t p = 0; p < pieces.size(); p++) {
     const Feeder::Piece &pc = pieces[p];
     const int c = pc.chunk, slot = c % nslots;
@@ -743,25 +1009,27 @@ int feed_chunks(const uint8_t *mem, int fd, size_t first, size_t rec, size_t ski
       F.abort = true;
       return fail("input file: read error");
     }
+    if (!pc.last_of_group) continue;
+    const int base = plan[c], m = plan[c + 1] - plan[c];
     uint8_t *chunk_dst = skip ? r.d_rec[slot] : r.d_images[slot];
-    // the chunk that had this buffer before: its stages (no label bytes) / its strip kernel (same stream: in order) are done
-    if (pc.off_in_chunk == 0 && c >= nslots) {
+    // the chunk that had this HBM buffer before: its stages (no label bytes) / its strip kernel (same stream: in order) are done
+    if (!chunk_open && c >= nslots) {
       if (!skip) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));
-      // (the second queue writes the same chunk buffer: behind chunk c-2's stages, or -- label bytes -- behind its strip
+      // (the second queue writes the same chunk buffer: behind chunk c-nslots's stages, or -- label bytes -- behind its strip
       // kernel, after which `copied` was recorded)
       if (F.aux) HIP_OK(hipStreamWaitEvent(F.aux, skip ? r.copied[slot] : r.consumed[slot], 0));
     }
-    hipStream_t ds = (F.aux && (p & 1)) ? F.aux : r.copy_stream;
-    HIP_OK(hipMemcpyAsync(chunk_dst + pc.off_in_chunk, F.ring + (p % Feeder::kSlots) * F.kSlotBytes, pc.bytes, hipMemcpyHostToDevice, ds));
-    HIP_OK(hipEventRecord(F.sent[p % Feeder::kSlots], ds));
-    issued = p + 1;
+    chunk_open = !pc.last_of_chunk;
+    hipStream_t ds = (F.aux && (pc.group & 1)) ? F.aux : r.copy_stream;
+    HIP_OK(hipMemcpyAsync(chunk_dst + pc.group_dst_off, F.ring + (size_t)(pc.group % Feeder::kSlots) * F.kSlotBytes, pc.group_bytes, hipMemcpyHostToDevice, ds));
+    HIP_OK(hipEventRecord(F.sent[pc.group % Feeder::kSlots], ds));
+    issued = (size_t)pc.group + 1;
     release_done();
     if (!pc.last_of_chunk) continue;
-    if (F.aux) {  // the chunk is complete when both queues have delivered their pieces
+    if (F.aux) {  // the chunk is complete when both queues have delivered their groups
       HIP_OK(hipEventRecord(F.aux_done, F.aux));
       HIP_OK(hipStreamWaitEvent(r.copy_stream, F.aux_done, 0));
     }
-    const int base = plan[c], m = plan[c + 1] - plan[c];
     if (skip) {
       if (c >= nslots) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));  // d_images[slot] free again
       const hipError_t e = launch_strip_records(r.d_rec[slot], (int)rec, (int)skip, r.d_images[slot], m, r.copy_stream);
@@ -772,68 +1040,6 @@ int feed_chunks(const uint8_t *mem, int fd, size_t first, size_t rec, size_t ski
     if (consume(c, base, m, slot)) return -1;
     HIP_OK(hipEventRecord(r.consumed[slot], lane_stream(c, lanes)));
   }
-  return 0;
-}
-
-// n host images -> any of classes / scores / words (host arrays), chunked.
-// usec: device time of the compute stages only, per image (the reference times
-// the accelerator call alone, foldedmv-offload.h:389-392).
-int infer_host(const uint8_t *imgs, int n, int ncls, int32_t *classes, int16_t *scores, uint64_t *words, float *usec) {
-  Runtime &r = rt();
-  if (!ready()) return -1;
-  if (ncls < 1 || ncls > 64) return fail("number_class must be in 1..64");
-  if (usec) *usec = 0.f;
-  if (n <= 0) return 0;
-  const size_t isz = (size_t)r.spec.image_bytes();
-  // (the stage-output test hook reads the workspace after the call: all images must be in it, one chunk)
-  const std::vector<int> plan = plan_chunks(n, r.debug_last_stage >= 0, false);
-  const int chunk = largest_chunk(plan);
-  const int nchunks = (int)plan.size() - 1;
-  // The pinned ring is for FILES.  A buffer in host memory goes faster without it: the runtime's own pageable path moves
-  // a 100 MB chunk at 54 GB/s (profiles/r03_h2d_probe.txt), the ring's 4-8 MB pieces reach 49-52 and add a copy
-  // (measured, same box: 13.8 ms through the ring, 12.7 ms without, 131 072 CIFAR images).  BNN_MI355X_FEED_HOST=1 forces it.
-  static const bool feed_host = std::getenv("BNN_MI355X_FEED_HOST") != nullptr;
-  const bool fed = feed_host && nchunks > 1 && use_feeder((size_t)n * isz);
-  const int lanes = lanes_for(nchunks);
-  const int nslots = slots_for(lanes);
-  if (reserve(chunk) || (lanes == 2 && reserve2(chunk)) || reserve_host(chunk, (size_t)n, nslots)) return -1;
-  while ((int)r.time_events.size() < 2 * nchunks) {
-    hipEvent_t e;
-    HIP_OK(hipEventCreateWithFlags(&e, kTimeEventFlags));
-    r.time_events.push_back(e);
-  }
-  DrainOnFailure drain;
-  const bool want_scores = scores && r.spec.is_cnv;
-  // Two staging buffers: the copy engine fills one while the stages consume the other.  Results of
-  // every chunk stay in HBM and come back in one transfer at the end (a D2H into pageable memory
-  // would otherwise make the host wait for each chunk's kernels before it can queue the next copy).
-  auto stages = [&](int c, int base, int m, int slot) {
-    return enqueue(r.d_images[slot], m, ncls, classes ? r.d_classes + base : nullptr, want_scores ? r.d_scores + (size_t)base * 64 : nullptr,
-                   r.d_words + base, lane_stream(c, lanes), r.time_events[2 * c], r.time_events[2 * c + 1], lanes == 2 ? (c & 1) : 0);
-  };
-  if (fed && feed_chunks(imgs, -1, 0, isz, 0, plan, lanes, stages)) return -1;
-  for (int c = 0; c < (fed ? 0 : nchunks); c++) {
-    const int base = plan[c], m = plan[c + 1] - plan[c], slot = c % nslots;
-    if (nchunks == 1) {  // nothing to overlap: stay on one stream (fewer driver round trips for small calls)
-      HIP_OK(hipMemcpyAsync(r.d_images[slot], imgs, (size_t)m * isz, hipMemcpyHostToDevice, r.stream));
-    } else {
-      if (c >= nslots) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));
-      HIP_OK(hipMemcpyAsync(r.d_images[slot], imgs + (size_t)base * isz, (size_t)m * isz, hipMemcpyHostToDevice, r.copy_stream));
-      HIP_OK(hipEventRecord(r.copied[slot], r.copy_stream));
-      HIP_OK(hipStreamWaitEvent(lane_stream(c, lanes), r.copied[slot], 0));
-    }
-    if (stages(c, base, m, slot)) return -1;
-    if (nchunks > 1) HIP_OK(hipEventRecord(r.consumed[slot], lane_stream(c, lanes)));
-  }
-  if (join_lanes(lanes)) return -1;
-  if (classes) HIP_OK(hipMemcpyAsync(classes, r.d_classes, (size_t)n * 4, hipMemcpyDeviceToHost, r.stream));
-  if (want_scores) HIP_OK(hipMemcpyAsync(scores, r.d_scores, (size_t)n * 128, hipMemcpyDeviceToHost, r.stream));
-  if (words && !r.spec.is_cnv) HIP_OK(hipMemcpyAsync(words, r.d_words, (size_t)n * 8, hipMemcpyDeviceToHost, r.stream));
-  HIP_OK(hipStreamSynchronize(r.stream));
-  double total_ms = 0.0;
-  if (chunks_device_ms(nchunks, &total_ms)) return -1;
-  if (usec) *usec = (float)(total_ms * 1000.0 / n);
-  drain.ok();
   return 0;
 }
 
@@ -856,6 +1062,16 @@ int warm_up() {
   if (r.spec.is_cnv) {  // the file path's label-stripping kernel lives in another code object
     const hipError_t e = launch_strip_records(r.d_images[0], 3073, 1, r.d_images[1], 2, r.stream);
     if (e != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(e));
+  } else {  // the forms that start from host-binarised words (the zeros read as 13-word images just as well)
+    for (int n : {1, 300, 600, 1100, 2500, big})
+      if (enqueue(r.d_images[0], n, 10, r.d_classes, nullptr, r.d_words, r.stream, nullptr, nullptr, 0, false, true)) return -1;
+  }
+  // the pinned I/O block of the direct calls, and one image through it
+  if (ensure_io()) return -1;
+  {
+    const ResultSlots m = mapped_results(1, r.spec.is_cnv);
+    if (m.d_classes && enqueue(r.spec.is_cnv ? r.d_io + 16 : r.d_io, 1, 10, m.d_classes, m.d_scores, m.d_words, r.stream, r.io_t0, r.io_t1, 0, true, !r.spec.is_cnv))
+      return -1;
   }
   while (r.time_events.size() < 2) {
     hipEvent_t e;
@@ -1019,20 +1235,192 @@ int stream_file(const ImageFile &f, int n, bool reuse_slots, int lanes, Dst dst,
   return 0;
 }
 
-// images [0, n) of an open file -> any of classes / scores / words (host arrays).  Same contract as
-// infer_host; the timed region is again the compute stages alone.
-int infer_file(const ImageFile &f, int n, int ncls, int32_t *classes, int16_t *scores, uint64_t *words, float *usec) {
+// ---- host buffers: the copies on a thread of their own -------------------------------------------------------
+// hipMemcpyAsync from PAGEABLE memory returns when the bytes have left (the runtime pins or stages the pages and waits for
+// its DMA): with copies and launches on one thread the link idles while the nine launches of every chunk are enqueued --
+// 20-45 us a chunk, 150-250 us of a 1.2 ms call of 10 000 CIFAR images (BNN_MI355X_TRACE: the copies alone ran at
+// 28-52 GB/s, the call's bytes arrived at 37).  So the copies of chunks 1.. are issued by a helper thread, back to back
+// on the copy stream, while the calling thread enqueues stages; chunk 0's copy stays with the caller (the helper needs
+// 30-60 us to wake up).  Two counters tie them together: `copied` (helper -> caller: chunks whose `copied` event is
+// recorded -- a stream may only be made to wait for an event that has been recorded) and `consumed` (caller -> helper:
+// chunks whose stages are enqueued and whose `consumed` event is recorded -- their HBM slot may be overwritten).
+// One per process, never destroyed (like the feeder's threads).
+struct Copier {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv, cv_idle;
+  bool started = false, busy = false;
+  uint64_t job_id = 0;
+  // the job
+  const uint8_t *src = nullptr;
+  const std::vector<int> *plan = nullptr;
+  size_t isz = 0;
+  int nslots = 2, device = 0;
+  std::atomic<int> copied{0}, consumed{0};
+  std::atomic<bool> abort{false}, failed{false};
+  std::string err;
+
+  void run() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return job_id != seen; });
+        seen = job_id;
+      }
+      Runtime &r = rt();
+      const int nchunks = (int)plan->size() - 1;
+      hipError_t e = hipSetDevice(device);
+      for (int c = 1; c < nchunks && e == hipSuccess; c++) {
+        const int slot = c % nslots, base = (*plan)[c], m = (*plan)[c + 1] - base;
+        // chunk c-1's copy is in the stream (the caller's for c = 1), and the chunk that had this slot is consumed
+        while (!abort.load(std::memory_order_relaxed) &&
+               (copied.load(std::memory_order_acquire) < c || (c >= nslots && consumed.load(std::memory_order_acquire) < c - nslots + 1)))
+          std::this_thread::yield();
+        if (abort.load(std::memory_order_relaxed)) break;
+        if (c >= nslots) e = hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(r.d_images[slot], src + (size_t)base * isz, (size_t)m * isz, hipMemcpyHostToDevice, r.copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(r.copied[slot], r.copy_stream);
+        if (e == hipSuccess) copied.store(c + 1, std::memory_order_release);
+      }
+      if (e != hipSuccess) {
+        err = std::string("host buffer copy: ") + hipGetErrorString(e);
+        failed.store(true, std::memory_order_release);
+      }
+      std::lock_guard<std::mutex> lk(mu);
+      busy = false;
+      cv_idle.notify_all();
+    }
+  }
+  void begin(const uint8_t *s, const std::vector<int> &p, size_t image_bytes, int slots, int dev) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!started) {
+      th = std::thread([this] { run(); });
+      th.detach();
+      started = true;
+    }
+    src = s; plan = &p; isz = image_bytes; nslots = slots; device = dev;
+    copied = 0; consumed = 0; abort = false; failed = false;
+    busy = true;
+    job_id++;
+    cv.notify_one();
+  }
+  // the helper has left the job: its description may go out of scope
+  void end() {
+    abort = true;  // (a no-op after a complete run)
+    std::unique_lock<std::mutex> lk(mu);
+    cv_idle.wait(lk, [&] { return !busy; });
+  }
+};
+Copier &copier() {
+  static Copier *c = new Copier;
+  return *c;
+}
+
+// ---- the entry points that take HOST data --------------------------------------------------------------------
+// n images from host memory (mem) or from an open input file -> any of classes / scores / words (host arrays).
+// usec: device time of the compute stages only, per image (the reference times the accelerator call alone,
+// foldedmv-offload.h:389-392, and excludes the transfers: TRANSFER_EXCL, foldedmv-offload.cpp:53-61).
+struct Source {
+  const uint8_t *mem = nullptr;     // n x image_bytes, as in the bodies of the file formats, or
+  const ImageFile *file = nullptr;  // an open CIFAR-10 binary / MNIST idx3 file
+};
+
+// Small calls -- one CIFAR image (classify_image and the webcam loops call inference(path) per frame,
+// bnn/bnn.py:131-137, main_python.cpp:120-139), up to kDirectMaxLfc MNIST images -- with no transfer at all: the image
+// (LFC: binarised here, 13 words each, like the reference's host does) is placed in pinned memory the GPU addresses,
+// the one-launch kernels read it over the link and write their results into pinned memory: launch, one wait.
+// words_view (optional, LFC): receives a pointer to the raw output words where the call left them in pinned memory,
+// valid until the next call into the library -- the batched decode reads them there instead of from a copy
+int infer_direct(const Source &src, int n, int ncls, int32_t *classes, int16_t *scores, uint64_t *words, float *usec, const uint64_t **words_view) {
+  Runtime &r = rt();
+  if (ensure_io() || reserve(n)) return -1;
+  trace().mark("reserved");
+  const uint8_t *d_in = r.d_io;
+  if (r.spec.is_cnv) {
+    // the kernels read an image with 128-bit loads: the body (3072 bytes behind the label byte) starts at +16
+    if (src.file) {
+      if (::pread(src.file->fd, r.h_io + 15, 3073, (off_t)src.file->first) != 3073) return fail("input file: read error");
+    } else {
+      std::memcpy(r.h_io + 16, src.mem, 3072);
+    }
+    d_in = r.d_io + 16;
+  } else if (src.file) {
+    const size_t bytes = (size_t)n * kLfcPixels;
+    if (r.h_scratch.size() < bytes) r.h_scratch.resize(bytes);
+    size_t done = 0;
+    while (done < bytes) {
+      const ssize_t got = ::pread(src.file->fd, r.h_scratch.data() + done, bytes - done, (off_t)(src.file->first + done));
+      if (got <= 0) return fail("input file: read error");
+      done += (size_t)got;
+    }
+    binarize_pack(r.h_scratch.data(), (size_t)n, reinterpret_cast<uint64_t *>(r.h_io));
+  } else {
+    binarize_pack(src.mem, (size_t)n, reinterpret_cast<uint64_t *>(r.h_io));
+  }
+  const bool want_scores = scores && r.spec.is_cnv;
+  const ResultSlots m = mapped_results(n, want_scores);
+  if (!m.d_classes) return fail("pinned I/O block unavailable");
+  DrainOnFailure drain;
+  trace().mark("input_placed");
+  if (enqueue(d_in, n, ncls, classes ? m.d_classes : nullptr, want_scores ? m.d_scores : nullptr, m.d_words, r.stream, r.io_t0, r.io_t1, 0, true,
+              !r.spec.is_cnv))
+    return -1;
+  trace().mark("launched");
+  // The wait: a blocking wait sleeps until the completion interrupt has made its way to this thread -- 15-25 us behind a
+  // 9 us kernel (BNN_MI355X_TRACE).  For calls this small the thread polls the stop event instead, for at most 300 us;
+  // whatever is not done by then gets the blocking wait.
+  {
+    const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(300);
+    hipError_t q;
+    while ((q = hipEventQuery(r.io_t1)) == hipErrorNotReady && std::chrono::steady_clock::now() < until) {}
+    if (q != hipSuccess) HIP_OK(hipStreamSynchronize(r.stream));
+  }
+  trace().mark("synced");
+  if (classes) std::memcpy(classes, m.h_classes, (size_t)n * 4);
+  if (want_scores) std::memcpy(scores, m.h_scores, (size_t)n * 128);
+  if (words && !r.spec.is_cnv) std::memcpy(words, m.h_words, (size_t)n * 8);
+  if (words_view) *words_view = m.h_words;
+  float ms = 0.f;
+  HIP_OK(hipEventElapsedTime(&ms, r.io_t0, r.io_t1));
+  if (usec) *usec = ms * 1000.f / (float)n;
+  drain.ok();
+  trace().mark("done");
+  trace().dump("direct");
+  return 0;
+}
+
+int infer_any(const Source &src, int n, int ncls, int32_t *classes, int16_t *scores, uint64_t *words, float *usec, const uint64_t **words_view = nullptr) {
   Runtime &r = rt();
   if (!ready()) return -1;
   if (ncls < 1 || ncls > 64) return fail("number_class must be in 1..64");
   if (usec) *usec = 0.f;
   if (n <= 0) return 0;
-  const std::vector<int> plan = plan_chunks(n, false, true);  // (stream_file walks the same plan)
+  if (!src.file) trace().start();  // (a file call started the clock before it opened the file)
+  const bool from_file = src.file != nullptr;
+  const bool hook = r.debug_last_stage >= 0;  // (the stage-output test hook reads the workspace after the call: all images in it, one chunk, device binarisation)
+  const bool want_scores = scores && r.spec.is_cnv;
+  static const bool no_direct = std::getenv("BNN_MI355X_NO_DIRECT") != nullptr;  // A/B
+  if (!hook && !r.profiling && !no_direct && n <= (r.spec.is_cnv ? kDirectMaxCnv : kDirectMaxLfc) && (!want_scores || n <= kMappedScoresMax))
+    return infer_direct(src, n, ncls, classes, scores, words, usec, words_view);
+  const size_t isz = (size_t)r.spec.image_bytes();
+  const size_t rec = from_file ? src.file->rec : isz, skip = from_file ? src.file->skip : 0, first = from_file ? src.file->first : 0;
+  const std::vector<int> plan = plan_chunks(n, hook, from_file);
   const int chunk = largest_chunk(plan);
   const int nchunks = (int)plan.size() - 1;
+  // LFC: binarizeAndPack on the host side of the copy, as the reference does (foldedmv-offload.cpp:82-98,186-194): worker
+  // threads turn 784 pixels into 13 words straight into pinned memory and 104 bytes per image cross the link (the raw pixels
+  // made every host-path call of the LFC nets PCIe-bound at 34-37 GB/s = 43 M images/s, against 230 M/s of stages).
+  static const bool no_pack = std::getenv("BNN_MI355X_NO_HOST_PACK") != nullptr;  // A/B: raw pixels to HBM, binarised there
+  const bool packed = !r.spec.is_cnv && !hook && !no_pack && feeder().init() == 0 && (size_t)chunk * kLfcWords * 8 <= feeder().kSlotBytes;
+  // The pinned ring is for FILES (and for the LFC nets' binarised words).  A CIFAR buffer in host memory goes faster without
+  // it: the runtime's own pageable path moves a 100 MB chunk at 54 GB/s (profiles/r03_h2d_probe.txt), the ring's 4-8 MB
+  // pieces reach 49-52 and add a copy (measured, same box: 13.8 ms through the ring, 12.7 ms without, 131 072 CIFAR
+  // images).  BNN_MI355X_FEED_HOST=1 forces it.
+  static const bool feed_host = std::getenv("BNN_MI355X_FEED_HOST") != nullptr;
   // large file: worker threads pread() it into the pinned ring piece by piece (feed_chunks); small: one or a few chunks
   // through a pageable host chunk (stream_file) -- also where the ring cannot be had (no pinned memory to spare): slower, same result
-  const bool ring = nchunks > 1 && use_feeder((size_t)n * f.rec) && feeder().init() == 0;
+  const bool ring = packed || ((from_file || feed_host) && nchunks > 1 && use_feeder((size_t)n * rec) && feeder().init() == 0);
   const int lanes = lanes_for(nchunks);
   const int nslots = slots_for(lanes);
   if (reserve(chunk) || (lanes == 2 && reserve2(chunk)) || reserve_host(chunk, (size_t)n, nslots)) return -1;
@@ -1041,25 +1429,88 @@ int infer_file(const ImageFile &f, int n, int ncls, int32_t *classes, int16_t *s
     HIP_OK(hipEventCreateWithFlags(&e, kTimeEventFlags));
     r.time_events.push_back(e);
   }
+  // results: small calls have the last stage write them into pinned memory (no copy back); larger ones keep them in HBM
+  // and fetch them with ONE transfer at the end (a D2H into pageable memory per chunk would make the host wait for each
+  // chunk's kernels before it can queue the next copy)
+  const ResultSlots m = hook ? ResultSlots{} : mapped_results(n, want_scores);
+  int32_t *const dc = m.d_classes ? m.d_classes : r.d_classes;
+  uint64_t *const dw = m.d_words ? m.d_words : r.d_words;
+  int16_t *const ds = m.d_scores ? m.d_scores : r.d_scores;
+  const bool want_words = (words || words_view) && !r.spec.is_cnv;
+  if (classes && !m.d_classes && grow_pinned(r.h_classes, r.h_classes_cap, (size_t)n)) return -1;
+  if (want_words && !m.d_words && grow_pinned(r.h_words, r.h_words_cap, (size_t)n)) return -1;
   DrainOnFailure drain;
-  const bool want_scores = scores && r.spec.is_cnv;
-  auto stages = [&](int c, int base, int m, int slot) {
-    return enqueue(r.d_images[slot], m, ncls, classes ? r.d_classes + base : nullptr, want_scores ? r.d_scores + (size_t)base * 64 : nullptr,
-                   r.d_words + base, lane_stream(c, lanes), r.time_events[2 * c], r.time_events[2 * c + 1], lanes == 2 ? (c & 1) : 0);
+  trace().mark("reserved");
+  auto stages = [&](int c, int base, int mm, int slot) {
+    trace().mark("chunk_in", c);
+    const int rc = enqueue(r.d_images[slot], mm, ncls, classes ? dc + base : nullptr, want_scores ? ds + (size_t)base * 64 : nullptr, dw + base,
+                           lane_stream(c, lanes), r.time_events[2 * c], r.time_events[2 * c + 1], lanes == 2 ? (c & 1) : 0, nchunks == 1, packed);
+    trace().mark("queued", c);
+    return rc;
   };
-  const int rc = ring ? feed_chunks(nullptr, f.fd, f.first, f.rec, f.skip, plan, lanes, stages)
-                      : stream_file(f, n, true, lanes, [&](int, int slot) { return r.d_images[slot]; }, stages);
-  if (rc || join_lanes(lanes)) return -1;
-  if (classes) HIP_OK(hipMemcpyAsync(classes, r.d_classes, (size_t)n * 4, hipMemcpyDeviceToHost, r.stream));
-  if (want_scores) HIP_OK(hipMemcpyAsync(scores, r.d_scores, (size_t)n * 128, hipMemcpyDeviceToHost, r.stream));
-  if (words && !r.spec.is_cnv) HIP_OK(hipMemcpyAsync(words, r.d_words, (size_t)n * 8, hipMemcpyDeviceToHost, r.stream));
+  if (ring) {
+    if (feed_chunks(src.mem, from_file ? src.file->fd : -1, first, rec, skip, plan, lanes, packed, stages)) return -1;
+  } else if (from_file) {
+    if (stream_file(*src.file, n, true, lanes, [&](int, int slot) { return r.d_images[slot]; }, stages)) return -1;
+  } else if (nchunks == 1) {  // nothing to overlap: stay on one stream (fewer driver round trips for small calls)
+    HIP_OK(hipMemcpyAsync(r.d_images[0], src.mem, (size_t)n * isz, hipMemcpyHostToDevice, r.stream));
+    if (stages(0, 0, n, 0)) return -1;
+  } else {
+    static const bool one_thread = std::getenv("BNN_MI355X_NO_COPIER") != nullptr;  // A/B: copies and launches on the calling thread
+    Copier &K = copier();
+    struct End {
+      Copier *k;
+      ~End() { if (k) k->end(); }
+    } end_guard{one_thread ? nullptr : &K};
+    if (!one_thread) K.begin(src.mem, plan, isz, nslots, r.device);  // (copies of chunks 1..: "the copies on a thread of their own" above)
+    for (int c = 0; c < nchunks; c++) {
+      const int base = plan[c], mm = plan[c + 1] - plan[c], slot = c % nslots;
+      if (one_thread || c == 0) {
+        if (c >= nslots) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));
+        HIP_OK(hipMemcpyAsync(r.d_images[slot], src.mem + (size_t)base * isz, (size_t)mm * isz, hipMemcpyHostToDevice, r.copy_stream));
+        HIP_OK(hipEventRecord(r.copied[slot], r.copy_stream));
+        if (!one_thread) K.copied.store(1, std::memory_order_release);
+      } else {
+        while (K.copied.load(std::memory_order_acquire) <= c) {
+          if (K.failed.load(std::memory_order_acquire)) return fail(K.err);
+          std::this_thread::yield();
+        }
+      }
+      HIP_OK(hipStreamWaitEvent(lane_stream(c, lanes), r.copied[slot], 0));
+      if (stages(c, base, mm, slot)) return -1;
+      HIP_OK(hipEventRecord(r.consumed[slot], lane_stream(c, lanes)));
+      if (!one_thread) K.consumed.store(c + 1, std::memory_order_release);
+    }
+  }
+  if (join_lanes(lanes)) return -1;
+  trace().mark("all_queued");
+  if (classes && !m.d_classes) HIP_OK(hipMemcpyAsync(r.h_classes, r.d_classes, (size_t)n * 4, hipMemcpyDeviceToHost, r.stream));
+  if (want_scores && !m.d_scores) HIP_OK(hipMemcpyAsync(scores, r.d_scores, (size_t)n * 128, hipMemcpyDeviceToHost, r.stream));
+  if (want_words && !m.d_words) HIP_OK(hipMemcpyAsync(r.h_words, r.d_words, (size_t)n * 8, hipMemcpyDeviceToHost, r.stream));
   HIP_OK(hipStreamSynchronize(r.stream));
-  HIP_OK(hipStreamSynchronize(r.copy_stream));
+  if (from_file) HIP_OK(hipStreamSynchronize(r.copy_stream));
+  trace().mark("synced");
+  if (classes) std::memcpy(classes, m.d_classes ? m.h_classes : r.h_classes, (size_t)n * 4);
+  if (want_scores && m.d_scores) std::memcpy(scores, m.h_scores, (size_t)n * 128);
+  if (words && !r.spec.is_cnv) std::memcpy(words, m.d_words ? m.h_words : r.h_words, (size_t)n * 8);
+  if (words_view) *words_view = m.d_words ? m.h_words : r.h_words;
   double total_ms = 0.0;
   if (chunks_device_ms(nchunks, &total_ms)) return -1;
   if (usec) *usec = (float)(total_ms * 1000.0 / n);
   drain.ok();
+  trace().mark("done");
+  trace().dump(ring ? (packed ? "ring, host-binarised" : "ring") : (from_file ? "pageable file chunks" : "pageable buffer"));
   return 0;
+}
+int infer_host(const uint8_t *imgs, int n, int ncls, int32_t *classes, int16_t *scores, uint64_t *words, float *usec, const uint64_t **words_view = nullptr) {
+  Source s;
+  s.mem = imgs;
+  return infer_any(s, n, ncls, classes, scores, words, usec, words_view);
+}
+int infer_file(const ImageFile &f, int n, int ncls, int32_t *classes, int16_t *scores, uint64_t *words, float *usec, const uint64_t **words_view = nullptr) {
+  Source s;
+  s.file = &f;
+  return infer_any(s, n, ncls, classes, scores, words, usec, words_view);
 }
 
 // all images of a file, packed, resident in HBM at r.d_all (fault campaigns classify them in runs)
@@ -1081,7 +1532,11 @@ uint64_t label_mask(int ncls) { return 0xFFFFFFFFFFFFFFFFull >> (64 - ncls); }
 // batched: (unsigned) log2((double) word), 0 when no bit is set (foldedmv-offload.cpp:213-220)
 int lfc_class_batched(uint64_t w, int ncls) {
   w &= label_mask(ncls);
-  return w ? (int)(unsigned int)std::log2((double)w) : 0;
+  // below 2^47 the double-precision log2 cannot round up to the next integer (2^k - 1 lies 1.44 * 2^-k below k, an ulp
+  // of k is 2^-47 for k >= 32): its truncation IS the index of the highest set bit -- without 131 072 calls into libm
+  // per LFC batch (0.8 ms of a 1.9 ms call, BNN_MI355X_TRACE).  Wider words go through libm like the reference's.
+  if ((w >> 47) == 0) return w ? 63 - __builtin_clzll(w) : 0;
+  return (int)(unsigned int)std::log2((double)w);
 }
 // single: index of the one-hot entry = round(log2(word)) (foldedmv-offload.cpp:152-165)
 int lfc_hot_single(uint64_t w, int ncls) {
@@ -1097,7 +1552,7 @@ int *classify_with(Infer infer, int n, int ncls, int enable_detail) {
   int *result = nullptr;
   if (r.spec.is_cnv && enable_detail) {
     std::vector<int16_t> s((size_t)n * 64);
-    if (infer(nullptr, s.data(), nullptr)) return nullptr;
+    if (infer(nullptr, s.data(), nullptr, nullptr)) return nullptr;
     result = new (std::nothrow) int[(size_t)(n > 0 ? n : 1) * ncls];
     if (!result) { fail("out of memory"); return nullptr; }
     for (int i = 0; i < n; i++)
@@ -1105,11 +1560,11 @@ int *classify_with(Infer infer, int n, int ncls, int enable_detail) {
   } else if (r.spec.is_cnv) {
     result = new (std::nothrow) int[(size_t)(n > 0 ? n : 1)];
     if (!result) { fail("out of memory"); return nullptr; }
-    if (infer(result, nullptr, nullptr)) { delete[] result; return nullptr; }
+    if (infer(result, nullptr, nullptr, nullptr)) { delete[] result; return nullptr; }
   } else {
     // the LFC libraries ignore enable_detail (lfcW1A1/sw/main_python.cpp:135-156)
-    std::vector<uint64_t> w((size_t)(n > 0 ? n : 1));
-    if (infer(nullptr, nullptr, w.data())) return nullptr;
+    const uint64_t *w = nullptr;  // the raw output words, where the call left them (pinned memory)
+    if (infer(nullptr, nullptr, nullptr, &w)) return nullptr;
     result = new (std::nothrow) int[(size_t)(n > 0 ? n : 1)];
     if (!result) { fail("out of memory"); return nullptr; }
     for (int i = 0; i < n; i++) result[i] = lfc_class_batched(w[i], ncls);
@@ -1118,7 +1573,7 @@ int *classify_with(Infer infer, int n, int ncls, int enable_detail) {
 }
 
 int *classify_host(const uint8_t *imgs, int n, int ncls, float *usec, int enable_detail) {
-  return classify_with([&](int32_t *c, int16_t *s, uint64_t *w) { return infer_host(imgs, n, ncls, c, s, w, usec); }, n, ncls,
+  return classify_with([&](int32_t *c, int16_t *s, uint64_t *w, const uint64_t **v) { return infer_host(imgs, n, ncls, c, s, w, usec, v); }, n, ncls,
                        enable_detail);
 }
 
@@ -1150,7 +1605,9 @@ int inference(const char *path, int results[64], int number_class, float *usecPe
   Runtime &r = rt();
   if (!ready()) return -1;
   ImageFile f;
+  trace().start();
   if (open_image_file(path, f)) return -1;
+  trace().mark("opened");
   if (f.n == 0) return fail("no image in input file");
   float usec = 0.f;
   int cls;
@@ -1181,10 +1638,12 @@ int *inference_multiple(const char *path, int number_class, int *image_number, f
                         int enable_detail) {
   if (!ready()) return nullptr;
   ImageFile f;
+  trace().start();
   if (open_image_file(path, f)) return nullptr;
+  trace().mark("opened");
   const int n = (int)f.n;
   float usec = 0.f;
-  int *res = classify_with([&](int32_t *c, int16_t *s, uint64_t *w) { return infer_file(f, n, number_class, c, s, w, &usec); }, n,
+  int *res = classify_with([&](int32_t *c, int16_t *s, uint64_t *w, const uint64_t **v) { return infer_file(f, n, number_class, c, s, w, &usec, v); }, n,
                            number_class, enable_detail);
   if (!res) return nullptr;
   std::printf("Inference took %.0f microseconds, %g usec per image\n", usec * n, usec);
@@ -1397,6 +1856,13 @@ int *bnn_mi355x_inference_buffer(const uint8_t *images, int n_images, int number
   if (!ready()) return nullptr;
   if (n_images < 0 || (n_images > 0 && !images)) { fail("inference_buffer: bad arguments"); return nullptr; }
   return classify_host(images, n_images, number_class, usecPerImage, enable_detail);
+}
+
+int bnn_mi355x_binarize_pack(const uint8_t *images, int n_images, uint64_t *words) {
+  if (rt().spec.is_cnv) return fail("binarize_pack: the CNV networks take 8-bit inputs (quantised on the GPU)");
+  if (n_images < 0 || (n_images > 0 && (!images || !words))) return fail("binarize_pack: bad arguments");
+  binarize_pack(images, (size_t)n_images, words);
+  return 0;
 }
 
 int bnn_mi355x_inference_raw(const uint8_t *images, int n_images, int16_t *scores, uint64_t *words,
@@ -1620,8 +2086,8 @@ int bnn_mi355x_inference_device(const void *d_images, int n_images, int number_c
   }
   hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(s, &capturing) != hipSuccess) capturing = hipStreamCaptureStatusNone;
-  for (int base = 0; base < n_images; base += kMaxChunk) {
-    const int m = (n_images - base < kMaxChunk) ? n_images - base : kMaxChunk;
+  // one pass of at most kMaxChunk images; returns -1 with the error in last_error
+  auto pass = [&](int base, int m) -> int {
     const uint8_t *img = static_cast<const uint8_t *>(d_images) + (size_t)base * isz;
     int32_t *cls = d_classes ? d_classes + base : nullptr;
     int16_t *sc = d_scores ? d_scores + (size_t)base * 64 : nullptr;
@@ -1634,35 +2100,44 @@ int bnn_mi355x_inference_device(const void *d_images, int n_images, int number_c
     // caller's stream is being captured into a graph, nor with stage profiling on (the stage events would time overlapping
     // kernels), nor under BNN_MI355X_LANES=1.
     const bool fork = r.spec.is_cnv && m >= kForkMin && lanes_for(3) == 2 && capturing == hipStreamCaptureStatusNone;
-    if (!fork) {
-      if (reserve(m) || enqueue(img, m, number_class, cls, sc, wd, s)) return -1;
-      continue;
-    }
+    if (!fork) return (reserve(m) || enqueue(img, m, number_class, cls, sc, wd, s)) ? -1 : 0;
     const int h = ((m / 2) + 255) & ~255;  // whole blocks of 256 images in the first half
-    if (reserve(h) || reserve2(m - h)) return -1;
+    // (the first workspace is sized for the WHOLE pass although this call uses half of it: the usual "warm-up call, then
+    // capture a call of the same size" sequence runs the captured call unforked, and it must not allocate while capturing)
+    if (reserve(m) || reserve2(m - h)) return -1;
     if (settle_handover(s)) return -1;  // (before the fork: the second lane inherits the wait through the fork event)
     HIP_OK(hipEventRecord(r.fork_ev, s));
     HIP_OK(hipStreamWaitEvent(r.stream2, r.fork_ev, 0));
     r.ws_seen[1] = r.ws_gen;
-    if (enqueue(img, h, number_class, cls, sc, wd, s)) return -1;
-    if (enqueue(img + (size_t)h * isz, m - h, number_class, cls ? cls + h : nullptr, sc ? sc + (size_t)h * 64 : nullptr, wd ? wd + h : nullptr,
-                r.stream2, nullptr, nullptr, 1))
-      return -1;
-    HIP_OK(hipEventRecord(r.lane2_done, r.stream2));
-    HIP_OK(hipStreamWaitEvent(s, r.lane2_done, 0));
-  }
-  // mark the end of this call's use of the shared workspace (not while the stream is being captured into a
-  // graph: a replayed graph is serialised by its own stream, and the caller must not replay it concurrently
-  // with other calls into this library -- include/bnn_mi355x.h)
-  if (n_images > 0 && s != r.stream) {
-    if (capturing == hipStreamCaptureStatusNone) {
-      HIP_OK(hipEventRecord(r.ws_event, s));
+    // From here on the second lane is tied to the caller's stream: whatever fails, the join still happens -- work already
+    // queued on the library's own stream must not outlive the call unseen (the next call on another stream waits for
+    // ws_event, which is recorded on `s` only).
+    const bool ok = enqueue(img, h, number_class, cls, sc, wd, s) == 0 &&
+                    enqueue(img + (size_t)h * isz, m - h, number_class, cls ? cls + h : nullptr, sc ? sc + (size_t)h * 64 : nullptr,
+                            wd ? wd + h : nullptr, r.stream2, nullptr, nullptr, 1) == 0;
+    const std::string why = r.err;
+    const bool joined = hipEventRecord(r.lane2_done, r.stream2) == hipSuccess && hipStreamWaitEvent(s, r.lane2_done, 0) == hipSuccess;
+    if (!joined) (void)hipStreamSynchronize(r.stream2);  // the join itself failed: settle it on the host
+    if (!ok) return fail(why);
+    return joined ? 0 : fail("inference_device: joining the second compute lane failed");
+  };
+  int rc = 0;
+  for (int base = 0; base < n_images && rc == 0; base += kMaxChunk) rc = pass(base, (n_images - base < kMaxChunk) ? n_images - base : kMaxChunk);
+  // mark the end of this call's use of the shared workspace -- on a failing exit too: passes queued before the failure
+  // still run (not while the stream is being captured into a graph: a replayed graph is serialised by its own stream, and
+  // the caller must not replay it concurrently with other calls into this library -- include/bnn_mi355x.h)
+  if (n_images > 0 && s != r.stream && capturing == hipStreamCaptureStatusNone) {
+    const std::string why = r.err;
+    if (hipEventRecord(r.ws_event, s) == hipSuccess) {
       r.ws_last = s;
       r.ws_pending = true;
       r.ws_gen++;
+    } else if (rc == 0) {
+      return fail("inference_device: recording the workspace hand-over failed");
     }
+    if (rc) r.err = why;
   }
-  return 0;
+  return rc;
 }
 
 }  // extern "C"

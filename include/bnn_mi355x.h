@@ -115,6 +115,14 @@ unsigned int bnn_mi355x_params_crc(void);
 int *bnn_mi355x_inference_buffer(const uint8_t *images, int n_images, int number_class,
                                  float *usecPerImage, int enable_detail);
 
+/* The LFC networks' input hand-over as the reference's host performs it (binarizeAndPack,
+ * bnn/src/library/host/foldedmv-offload.cpp:82-98, called per image at :186-188): n images of 784 uint8 pixels ->
+ * n x 13 little-endian 64-bit words, bit i = (pixel i >= 128), bits 784..831 zero.  This is what the entry points
+ * that take HOST data (inference_multiple, inference_buffer, inference_raw) run on worker threads so that 104 bytes
+ * per image cross the PCIe link instead of 784 (images already in HBM -- inference_device -- are binarised by the
+ * kernels).  Host only, touches no GPU; LFC libraries only (-1 + last_error on a CNV library).  Returns 0. */
+int bnn_mi355x_binarize_pack(const uint8_t *images, int n_images, uint64_t *words);
+
 /* Raw outputs for n host images: CNV scores[n*64] (16-bit, all 64 neurons of
  * layer 8), LFC words[n] (raw 64-bit output word).  Either may be NULL.
  * Returns 0 on success. */

@@ -471,6 +471,18 @@ static int lfc_forward_ref(const bnn_oracle *o, const uint8_t *px, int upto, int
   return count;
 }
 
+/* binarizeAndPack itself (foldedmv-offload.cpp:82-98), the words the reference's host ships to the accelerator
+ * (:186-194): memset to FOLDEDMV_INPUT_PADCHAR (0), then bit i of word i / 64 set where in[i] >= 0, in[i] being
+ * tiny-cnn's float scaling of pixel i to [-1, 1]. */
+void bnn_oracle_lfc_binarize(const uint8_t *px, uint64_t words[13]) {
+  memset(words, 0, 13 * sizeof(uint64_t));
+  for (int i = 0; i < 784; i++) {
+    const float x = ((float)px[i] / 255.0f) * (1.0f - (-1.0f)) + (-1.0f);
+    if (x >= 0) words[i / 64] |= (uint64_t)1 << (i % 64);
+    else words[i / 64] &= ~((uint64_t)1 << (i % 64));
+  }
+}
+
 uint64_t bnn_oracle_lfc_word_ref(const bnn_oracle *o, const uint8_t *px) {
   int8_t out[1024];
   lfc_forward_ref(o, px, 3, out);

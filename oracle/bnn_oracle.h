@@ -46,6 +46,8 @@ void bnn_oracle_cnv_scores_ref(const bnn_oracle *o, const uint8_t *img,
 /* px: 784 MNIST pixels row-major. Returns the raw 64-bit output word of the
  * last layer (lfcW1A1/hw/top.cpp:155-164), not yet masked to labelBits. */
 uint64_t bnn_oracle_lfc_word_ref(const bnn_oracle *o, const uint8_t *px);
+/* binarizeAndPack (foldedmv-offload.cpp:82-98): 784 pixels -> the 13 words the host ships to the accelerator */
+void bnn_oracle_lfc_binarize(const uint8_t *px, uint64_t words[13]);
 /* Activations after layer `layer` (after the max-pool that follows layers 1
  * and 3 of the CNV nets), value domain (+1/-1 for 1-bit activations,
  * -1/0/+1 for 2-bit), pixel-major HWC / neuron order.  For the last CNV layer

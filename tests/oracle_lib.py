@@ -58,6 +58,8 @@ def lib():
     L.bnn_oracle_layer_mw.argtypes = [vp, C.c_int]
     L.bnn_oracle_apply_fault.argtypes = [vp] + [C.c_int] * 7
     L.bnn_oracle_layer_mh.argtypes = [vp, C.c_int]
+    L.bnn_oracle_lfc_binarize.argtypes = [C.POINTER(C.c_uint8), C.POINTER(C.c_uint64)]
+    L.bnn_oracle_lfc_binarize.restype = None
     _lib = L
     return L
 
@@ -120,6 +122,14 @@ class Oracle:
                                         out.ctypes.data_as(C.POINTER(C.c_int8)), out.size)
         assert n >= 0
         return out[:n].copy()
+
+    def binarize(self, imgs):
+        """binarizeAndPack of every image: uint64 [n, 13]"""
+        imgs = np.ascontiguousarray(imgs, np.uint8).reshape(-1, 784)
+        out = np.zeros((imgs.shape[0], 13), np.uint64)
+        for i in range(imgs.shape[0]):
+            self.L.bnn_oracle_lfc_binarize(_u8(imgs[i]), out[i].ctypes.data_as(C.POINTER(C.c_uint64)))
+        return out
 
     # -- fast ---------------------------------------------------------------
     def scores_fast(self, imgs, nthreads=0):

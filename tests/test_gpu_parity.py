@@ -721,11 +721,12 @@ def test_device_call_captured_into_a_graph_after_a_call_on_another_stream():
     assert (out_a.cpu().numpy() == o.classes_batched(a_host, 10)).all()
 
 
-@pytest.mark.parametrize("n", [7809, 7811, 9999])
+@pytest.mark.parametrize("n", [681, 683, 1025, 7811, 9999])
 def test_file_abi_either_side_of_the_pinned_ring_threshold(n, tmp_path):
-    """files below 24 MB (7 810 CIFAR records) go through a pageable host chunk, larger ones through the ring of pinned
-    pieces that worker threads fill with pread() (feed_chunks): every class of an odd-sized file on both sides, against
-    the oracle; twice in a row (the ring's slots and the workers are reused)"""
+    """files below 2 MB (682 CIFAR records) go through a pageable host chunk, larger ones through the ring of pinned
+    pieces that worker threads fill with pread() (feed_chunks: a first chunk in 256 KB pieces, the calling thread filling
+    the first of them itself): every class of an odd-sized file on both sides, against the oracle; twice in a row (the
+    ring's slots and the workers are reused)"""
     net = gpu_net("cnvW1A1", "cifar10")
     imgs = rand_images("cnvW1A1", n, 4000 + n)
     rec = np.empty((n, 3073), np.uint8)
@@ -789,7 +790,7 @@ def test_host_paths_on_two_compute_lanes(tmp_path):
         edges = set()
         for from_file in (0, 1):
             nb = net.L.bnn_mi355x_chunk_plan(n, from_file, bases, 64)
-            assert nb >= 4                                            # three or more chunks: two lanes (files: > 24 MB, ring-fed)
+            assert nb >= 4                                            # three or more chunks: two lanes (files: ring-fed)
             edges |= {bases[i] for i in range(nb)}
         _oracle_sample(o, imgs, want, edges, n)
         path = str(tmp_path / (network + ".bin"))

@@ -46,7 +46,8 @@ CHECKS = [
     ("k_vec<2, 16, true, false, 1, 1, 32, false, false>", ("v_bitop3_b32",), 64, 10),
     # one-launch LFC kernel: per image 2 * 16 pairs (weights in VGPRs, the image in SGPRs), then the ballot (v_cmp)
     # and two v_writelane
-    ("k_lfc_block_s", ("v_xor_b32",), 32, 4, ("v_cmp",)),
+    ("k_lfc_block_s<false>", ("v_xor_b32",), 32, 4, ("v_cmp",)),
+    ("k_lfc_block_s<true>", ("v_xor_b32",), 32, 4, ("v_cmp",)),   # the same from host-binarised words (csrc/pack_inputs.h)
 ]
 FORBIDDEN = ("v_cmp", "v_cndmask", "v_mov_b32")
 SLACK_VALU, SLACK_BUBBLES = 4, 2
