@@ -20,6 +20,7 @@
 #include <immintrin.h>
 #endif
 #include <sys/stat.h>
+#include <sys/uio.h>
 #include <sched.h>
 #include <unistd.h>
 
@@ -222,9 +223,6 @@ struct Runtime {
   size_t file_cap = 0;
   std::unique_ptr<uint8_t[]> h_file[2];
   uint8_t *d_file[2] = {nullptr, nullptr};
-  size_t d_rec_cap = 0;  // feeder path: capacity of d_rec[] (records as they lie on disk, label bytes included)
-  int rec_slots = 0;
-  uint8_t *d_rec[kStageSlots] = {};
   hipEvent_t file_sent[2] = {nullptr, nullptr};
   uint8_t *d_all = nullptr;  // a whole input file's images, resident (fault campaigns)
   size_t all_cap = 0;
@@ -360,7 +358,7 @@ int upload_blob() {
 
 void free_workspace() {
   Runtime &r = rt();
-  if (r.cap == 0 && r.cap2 == 0 && r.stage_cap == 0 && r.res_cap == 0 && !r.d_pp_src && !r.d_pp_rec && !r.file_cap && !r.all_cap && !r.d_rec_cap && !r.h_io &&
+  if (r.cap == 0 && r.cap2 == 0 && r.stage_cap == 0 && r.res_cap == 0 && !r.d_pp_src && !r.d_pp_rec && !r.file_cap && !r.all_cap && !r.h_io &&
       !r.h_classes && !r.h_words)
     return;
   if (r.device >= 0) (void)hipSetDevice(r.device);
@@ -387,9 +385,6 @@ void free_workspace() {
   r.all_cap = 0;
   (void)hipFree(r.d_file[0]); (void)hipFree(r.d_file[1]);
   r.d_file[0] = r.d_file[1] = nullptr;
-  for (auto &b : r.d_rec) { (void)hipFree(b); b = nullptr; }
-  r.d_rec_cap = 0;
-  r.rec_slots = 0;
   r.h_file[0].reset(); r.h_file[1].reset();
   r.file_cap = 0;
   (void)hipFree(r.d_pp_src); (void)hipFree(r.d_pp_tmp); (void)hipFree(r.d_pp_rec); (void)hipFree(r.d_pp_coef);
@@ -504,6 +499,15 @@ int chunks_device_ms(int nchunks, double *out) {
     if (c) HIP_OK(hipEventElapsedTime(&a, r.time_events[0], r.time_events[2 * c]));
     HIP_OK(hipEventElapsedTime(&d, r.time_events[2 * c], r.time_events[2 * c + 1]));
     iv[(size_t)c] = {a, a + d};
+  }
+  if (trace().on) {  // when each chunk's stages ran on the device, microseconds from the first chunk's start
+    std::string line = "bnn-mi355x trace device intervals of the chunks (start-end us):";
+    char buf[48];
+    for (auto &x : iv) {
+      std::snprintf(buf, sizeof buf, " %.0f-%.0f", x.first * 1e3, x.second * 1e3);
+      line += buf;
+    }
+    std::fprintf(stderr, "%s\n", line.c_str());
   }
   std::sort(iv.begin(), iv.end());
   double total = 0.0;
@@ -722,10 +726,15 @@ struct Feeder {
   struct Piece {
     int chunk, group;
     size_t ring_off;   // where in the group's ring slot this piece's output goes
-    size_t src_off, bytes;
+    size_t src_off;    // of its first item (record / image) in the source
+    size_t items;
     bool last_of_group, last_of_chunk;
     size_t group_dst_off, group_bytes;  // (on the last piece of a group) the group's place in the chunk's HBM buffer and its size
   };
+  // the items of the job in flight: `rec` source bytes each, of which the first `skip` are dropped (the label byte of a
+  // CIFAR-10 record: the readers scatter the records with preadv() so that only the image bodies land in the ring -- no
+  // label bytes cross the link and no kernel has to remove them)
+  size_t rec = 0, skip = 0;
   uint8_t *ring = nullptr;  // kSlots x kSlotBytes, pinned
   bool ready = false;       // init() went through: ring, events, streams and workers exist
   hipEvent_t sent[kSlots] = {};
@@ -770,22 +779,55 @@ struct Feeder {
   }
   bool fill(const Piece &pc, uint8_t *dst) const {
     if (packed) {
-      const size_t images = pc.bytes / kLfcPixels;
-      if (mem) { binarize_pack(mem + pc.src_off, images, reinterpret_cast<uint64_t *>(dst)); return true; }
+      if (mem) { binarize_pack(mem + pc.src_off, pc.items, reinterpret_cast<uint64_t *>(dst)); return true; }
       // from a file: the pixels pass through a cache-sized scratch block on their way to the binariser
       constexpr size_t kBlock = 80;  // images: 62 720 bytes
       uint8_t scratch[kBlock * kLfcPixels];
-      for (size_t i = 0; i < images; i += kBlock) {
-        const size_t m = images - i < kBlock ? images - i : kBlock;
+      for (size_t i = 0; i < pc.items; i += kBlock) {
+        const size_t m = pc.items - i < kBlock ? pc.items - i : kBlock;
         if (!read_all(scratch, m * kLfcPixels, pc.src_off + i * kLfcPixels)) return false;
         binarize_pack(scratch, m, reinterpret_cast<uint64_t *>(dst) + i * kLfcWords);
       }
       return true;
     }
-    if (mem) { std::memcpy(dst, mem + pc.src_off, pc.bytes); return true; }
-    if (!read_all(dst, pc.bytes, pc.src_off)) return false;
+    const size_t body = rec - skip;
+    if (skip == 0) {
+      if (mem) { std::memcpy(dst, mem + pc.src_off, pc.items * rec); return true; }
+      if (!read_all(dst, pc.items * rec, pc.src_off)) return false;
+    } else if (mem) {
+      for (size_t i = 0; i < pc.items; i++) std::memcpy(dst + i * body, mem + pc.src_off + i * rec + skip, body);
+      return true;
+    } else {
+      // label bytes into a bin, bodies side by side: two iovecs per record, IOV_MAX (1024) per call
+      constexpr size_t kBatch = 512;
+      static_assert(2 * kBatch <= 1024, "IOV_MAX");
+      struct iovec iov[2 * kBatch];
+      uint8_t bin[64];
+      if (skip > sizeof bin) return false;
+      for (size_t i = 0; i < pc.items; i += kBatch) {
+        const size_t m = pc.items - i < kBatch ? pc.items - i : kBatch;
+        for (size_t k = 0; k < m; k++) {
+          iov[2 * k] = {bin, skip};
+          iov[2 * k + 1] = {dst + (i + k) * body, body};
+        }
+        size_t want = m * rec, done = 0;
+        off_t off = (off_t)(pc.src_off + i * rec);
+        int first_iov = 0;
+        while (done < want) {
+          const ssize_t got = ::preadv(fd, iov + first_iov, (int)(2 * m) - first_iov, off + (off_t)done);
+          if (got <= 0) return false;
+          done += (size_t)got;
+          if (done < want) {  // a short read: step over the iovecs that are full, trim the one that is not
+            size_t g = (size_t)got;
+            while (g >= iov[first_iov].iov_len) g -= iov[first_iov++].iov_len;
+            iov[first_iov].iov_base = static_cast<uint8_t *>(iov[first_iov].iov_base) + g;
+            iov[first_iov].iov_len -= g;
+          }
+        }
+      }
+    }
 #if defined(__x86_64__)
-    if (flush) flush_lines(dst, pc.bytes);
+    if (flush) flush_lines(dst, pc.items * body);
 #endif
     return true;
   }
@@ -862,7 +904,7 @@ struct Feeder {
     ready = true;
     return 0;
   }
-  void begin(const std::vector<Piece> &pcs, const uint8_t *m, int f, bool pack) {
+  void begin(const std::vector<Piece> &pcs, const uint8_t *m, int f, bool pack, size_t item_bytes, size_t drop) {
     if (pcs.size() > filled_cap) {
       filled.reset(new std::atomic<uint8_t>[pcs.size()]);
       filled_cap = pcs.size();
@@ -875,7 +917,7 @@ struct Feeder {
     }
     {
       std::lock_guard<std::mutex> lk(mu);
-      pieces = &pcs; mem = m; fd = f; packed = pack;
+      pieces = &pcs; mem = m; fd = f; packed = pack; rec = item_bytes; skip = drop;
       const int want = pack ? (int)workers.size() : raw_workers;
       // (no more threads than pieces: a thread woken for nothing still has to be waited for at the end)
       job_workers = (size_t)want < pcs.size() ? want : (int)pcs.size();
@@ -924,8 +966,8 @@ bool use_feeder(size_t bytes) {
 
 // n images from host memory (fd < 0) or from an open file, cut by `plan`, through the pinned ring into the HBM chunk
 // buffers; consume(c, base, m, slot) enqueues chunk c's stages on its lane's stream (lane_stream) once its bytes
-// (RAW: label bytes stripped, rec > isz; PACKED: 13 words per image) are in r.d_images[slot] and that stream has been
-// made to wait for them.
+// (RAW: the image bodies, the readers having dropped the `skip` label bytes of every record; PACKED: 13 words per image)
+// are in r.d_images[slot] and that stream has been made to wait for them.
 template <typename Consume>
 int feed_chunks(const uint8_t *mem, int fd, size_t first, size_t rec, size_t skip, const std::vector<int> &plan, int lanes, bool packed, Consume consume) {
   Runtime &r = rt();
@@ -934,59 +976,44 @@ int feed_chunks(const uint8_t *mem, int fd, size_t first, size_t rec, size_t ski
   const int nchunks = (int)plan.size() - 1, nslots = slots_for(lanes);
   if (packed && (skip || rec != (size_t)kLfcPixels || (size_t)largest_chunk(plan) * kLfcWords * 8 > F.kSlotBytes))
     return fail("internal: packed feed of a chunk that does not fit a ring slot");
-  if (skip) {  // records go to HBM as they lie on disk; k_strip_records drops the label bytes
-    size_t need = (size_t)largest_chunk(plan) * rec + 256;
-    if (need > r.d_rec_cap || nslots > r.rec_slots) {
-      HIP_OK(hipDeviceSynchronize());
-      if (need < r.d_rec_cap) need = r.d_rec_cap;
-      const int want = nslots > r.rec_slots ? nslots : r.rec_slots;
-      for (auto &b : r.d_rec) {
-        (void)hipFree(b);
-        b = nullptr;
-      }
-      r.d_rec_cap = 0;
-      r.rec_slots = 0;
-      for (int i = 0; i < want; i++) HIP_OK(hipMalloc(reinterpret_cast<void **>(&r.d_rec[i]), need));
-      r.d_rec_cap = need;
-      r.rec_slots = want;
-    }
-  }
   // Groups (DMAs) start small and double -- the first one is what everything else waits for --, the pieces inside them are
   // small throughout; the first chunk is one group in the smallest pieces, so that all workers share it.
   std::vector<Feeder::Piece> pieces;
-  const size_t unit = packed ? (size_t)kLfcPixels : 1;                       // source bytes per ring byte unit
-  const size_t piece0 = packed ? 256 * unit : (256u << 10), piece1 = packed ? 1024 * unit : (512u << 10);
-  size_t group_want = 1u << 20;                                             // RAW: 1, 2, 4 MB ...; PACKED: a chunk is a group
+  const size_t out = packed ? (size_t)kLfcWords * 8 : rec - skip;          // ring / HBM bytes per item
+  const size_t piece0 = packed ? 256 : (256u << 10) / rec, piece1 = packed ? 1024 : (512u << 10) / rec;  // items per piece
+  const size_t group_max = F.kSlotBytes / out;                              // items per group at most
+  size_t group_want = (1u << 20) / out;                                     // RAW: 1, 2, 4 MB ...; PACKED: a chunk is a group
   int ngroups = 0;
   for (int c = 0; c < nchunks; c++) {
-    const size_t bytes = (size_t)(plan[c + 1] - plan[c]) * rec, src0 = first + (size_t)plan[c] * rec;
-    for (size_t g0 = 0; g0 < bytes;) {
-      size_t gb = bytes - g0;
+    const size_t items = (size_t)(plan[c + 1] - plan[c]), src0 = first + (size_t)plan[c] * rec;
+    for (size_t g0 = 0; g0 < items;) {
+      size_t gi = items - g0;
       if (!packed) {
-        const size_t cap = c == 0 ? F.kSlotBytes : group_want;
-        if (gb > cap) gb = cap;
-        if (bytes - g0 - gb < gb / 4 && bytes - g0 <= F.kSlotBytes) gb = bytes - g0;  // (no crumb of a group at the end of a chunk)
-        if (c > 0) group_want = group_want * 2 < F.kSlotBytes ? group_want * 2 : F.kSlotBytes;
+        const size_t cap = c == 0 ? group_max : group_want;
+        if (gi > cap) gi = cap;
+        if (items - g0 - gi < gi / 4 && items - g0 <= group_max) gi = items - g0;  // (no crumb of a group at the end of a chunk)
+        if (c > 0) group_want = group_want * 2 < group_max ? group_want * 2 : group_max;
       }
       const size_t psz = c == 0 ? piece0 : piece1;
-      for (size_t o = 0; o < gb;) {
-        const size_t b = gb - o < psz ? gb - o : psz;
+      for (size_t o = 0; o < gi;) {
+        const size_t b = gi - o < psz ? gi - o : psz;
         Feeder::Piece pc{};
         pc.chunk = c; pc.group = ngroups;
-        pc.ring_off = packed ? o / kLfcPixels * kLfcWords * 8 : o;
-        pc.src_off = src0 + g0 + o; pc.bytes = b;
-        pc.last_of_group = o + b == gb;
-        pc.last_of_chunk = pc.last_of_group && g0 + gb == bytes;
-        pc.group_dst_off = packed ? g0 / kLfcPixels * kLfcWords * 8 : g0;
-        pc.group_bytes = packed ? gb / kLfcPixels * kLfcWords * 8 : gb;
+        pc.ring_off = o * out;
+        pc.src_off = src0 + (g0 + o) * rec;
+        pc.items = b;
+        pc.last_of_group = o + b == gi;
+        pc.last_of_chunk = pc.last_of_group && g0 + gi == items;
+        pc.group_dst_off = g0 * out;
+        pc.group_bytes = gi * out;
         pieces.push_back(pc);
         o += b;
       }
-      g0 += gb;
+      g0 += gi;
       ngroups++;
     }
   }
-  F.begin(pieces, mem, fd, packed);
+  F.begin(pieces, mem, fd, packed, rec, skip);
   struct End {
     Feeder &f;
     ~End() { f.end(); }
@@ -1011,13 +1038,11 @@ int feed_chunks(const uint8_t *mem, int fd, size_t first, size_t rec, size_t ski
     }
     if (!pc.last_of_group) continue;
     const int base = plan[c], m = plan[c + 1] - plan[c];
-    uint8_t *chunk_dst = skip ? r.d_rec[slot] : r.d_images[slot];
-    // the chunk that had this HBM buffer before: its stages (no label bytes) / its strip kernel (same stream: in order) are done
+    uint8_t *chunk_dst = r.d_images[slot];
+    // the chunk that had this HBM buffer before: its stages are done (both DMA queues write the buffer)
     if (!chunk_open && c >= nslots) {
-      if (!skip) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));
-      // (the second queue writes the same chunk buffer: behind chunk c-nslots's stages, or -- label bytes -- behind its strip
-      // kernel, after which `copied` was recorded)
-      if (F.aux) HIP_OK(hipStreamWaitEvent(F.aux, skip ? r.copied[slot] : r.consumed[slot], 0));
+      HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));
+      if (F.aux) HIP_OK(hipStreamWaitEvent(F.aux, r.consumed[slot], 0));
     }
     chunk_open = !pc.last_of_chunk;
     hipStream_t ds = (F.aux && (pc.group & 1)) ? F.aux : r.copy_stream;
@@ -1029,11 +1054,6 @@ int feed_chunks(const uint8_t *mem, int fd, size_t first, size_t rec, size_t ski
     if (F.aux) {  // the chunk is complete when both queues have delivered their groups
       HIP_OK(hipEventRecord(F.aux_done, F.aux));
       HIP_OK(hipStreamWaitEvent(r.copy_stream, F.aux_done, 0));
-    }
-    if (skip) {
-      if (c >= nslots) HIP_OK(hipStreamWaitEvent(r.copy_stream, r.consumed[slot], 0));  // d_images[slot] free again
-      const hipError_t e = launch_strip_records(r.d_rec[slot], (int)rec, (int)skip, r.d_images[slot], m, r.copy_stream);
-      if (e != hipSuccess) return fail(std::string("kernel launch: ") + hipGetErrorString(e));
     }
     HIP_OK(hipEventRecord(r.copied[slot], r.copy_stream));
     HIP_OK(hipStreamWaitEvent(lane_stream(c, lanes), r.copied[slot], 0));
