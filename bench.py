@@ -180,10 +180,11 @@ PAIRS_PER_WORD = {"W1A1": 2, "W1A2": 2, "W2A2": 4}  # (logic op + v_bcnt) pairs 
 PAIR_CYC_OF = {"W1A1": PAIR_CYC, "W1A2": 6.6, "W2A2": 6.35}
 
 
-def issue_floor_cycles(network):
-    """SIMD-cycles per image if the integer pipe issued nothing but the unavoidable instructions"""
+def issue_floor_cycles(network, pair_cycles=None):
+    """SIMD-cycles per image if the integer pipe issued nothing but the unavoidable instructions (pair_cycles: cycles per
+    (logic op, v_bcnt) pair measured in this run instead of the constant)"""
     kind, prec = network[:3], network[3:]
-    cyc = WORD_MACS[kind] * PAIRS_PER_WORD[prec] * PAIR_CYC_OF[prec]
+    cyc = WORD_MACS[kind] * PAIRS_PER_WORD[prec] * (pair_cycles if pair_cycles else PAIR_CYC_OF[prec])
     if kind == "cnv":
         # layer 0 runs on the matrix pipe (k_conv0_tile); what stays on the integer pipe per tile (one output row: 30 live
         # pixel lanes of 32) and lane: one v_alignbit per result (32), one v_alignbyte per 3-tap run (5), shifts / merge /
@@ -194,7 +195,150 @@ def issue_floor_cycles(network):
     return cyc / 64.0                                # 64 lanes per wave instruction
 
 
-def measure_config(network, dataset, batch, dev, device_index, steps, warmup, check=2048):
+def calibrate_issue(settle_ms=150):
+    """The integer-pipe issue ceiling measured on THIS device, outside every timed region (tools/issue_probe.hip): SIMD-cycles per
+    (logic op, v_bcnt) pair in the cadence the product kernels are built to, for the three arithmetic forms, at 4 and 8 waves per
+    SIMD, and the clock the device holds under that load (s_memtime / s_memrealtime).  The constants above (round-1 microbenchmarks,
+    another box) stay as the `peak` every round has quoted; `peak_measured` / `frac_measured` next to them use these figures."""
+    lib = os.path.join(ROOT, "tools", "libissue_probe.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950",
+                        os.path.join(ROOT, "tools", "issue_probe.hip"), "-o", lib], check=True)
+    P = C.CDLL(lib)
+    P.issue_probe_run.argtypes = [C.c_int, C.c_int, C.c_int] + [C.POINTER(C.c_double)] * 4
+    out = {"source": "tools/issue_probe.hip on this device, outside the timed regions: 16 pairs per asm statement, one s_nop 0 behind each pair, "
+                     "4 accumulator chains, SGPR weight, ~1.7 ms launches after 150 ms of the same load.  pair_cycles_measured = the launch's "
+                     "duration (HIP events) x the clock / pairs issued per SIMD, the better of 4 and 8 waves per SIMD -- the way the round-1 "
+                     "constants were taken; pair_cycles_in_kernel = s_memtime around the loop of the median block at 4 waves per SIMD (every "
+                     "block resident) / pairs per SIMD: the loop alone, without the launch; clock = s_memtime / s_memrealtime x 100 MHz",
+           "pair_cycles_measured": {}, "pair_cycles_in_kernel": {}, "clock_ghz_measured": {}, "by_waves_per_simd": {}}
+    for prec, pat in (("W1A1", 0), ("W1A2", 1), ("W2A2", 2)):
+        rows = {}
+        for w in (4, 8):
+            wall, kern, mhz, ms = C.c_double(0), C.c_double(0), C.c_double(0), C.c_double(0)
+            if P.issue_probe_run(pat, w, settle_ms if w == 4 else 30, C.byref(wall), C.byref(kern), C.byref(mhz), C.byref(ms)) != 0:
+                return {"error": "issue_probe_run(%d, %d) failed" % (pat, w)}
+            rows[str(w)] = {"pair_cycles_wall": round(wall.value, 3), "pair_cycles_in_kernel": round(kern.value, 3),
+                            "clock_ghz": round(mhz.value / 1e3, 4), "launch_ms": round(ms.value, 4)}
+        best = min(rows.values(), key=lambda r: r["pair_cycles_wall"])
+        out["pair_cycles_measured"][prec] = best["pair_cycles_wall"]
+        out["pair_cycles_in_kernel"][prec] = rows["4"]["pair_cycles_in_kernel"]
+        out["clock_ghz_measured"][prec] = best["clock_ghz"]
+        out["by_waves_per_simd"][prec] = rows
+    return out
+
+
+def valu_measured(network, rate_per_gpu, cal):
+    """`peak_measured` / `frac_measured` of one network from calibrate_issue()'s figures (None when the probe failed)"""
+    if not cal or "error" in cal:
+        return {}
+    prec = network[3:]
+    cyc = issue_floor_cycles(network, pair_cycles=cal["pair_cycles_measured"][prec])
+    clk = cal["clock_ghz_measured"][prec] * 1e9
+    peak = N_SIMD * clk / cyc
+    # the same with the loop's in-kernel rate (no launch in it): the hardware's own issue rate for this instruction mix
+    peak_k = N_SIMD * clk / issue_floor_cycles(network, pair_cycles=cal["pair_cycles_in_kernel"][prec])
+    return {"peak_measured": round(peak, 1), "frac_measured": round(rate_per_gpu / peak, 4),
+            "pair_cycles_measured": cal["pair_cycles_measured"][prec], "clock_ghz_measured": cal["clock_ghz_measured"][prec],
+            "peak_in_kernel_rate": round(peak_k, 1), "frac_of_in_kernel_rate": round(rate_per_gpu / peak_k, 4),
+            "pair_cycles_in_kernel": cal["pair_cycles_in_kernel"][prec]}
+
+
+def write_input_file(f, imgs, is_cnv):
+    """the reference's input formats: CIFAR-10 binary records (label byte + 3072) / an MNIST idx3 file"""
+    n = imgs.shape[0]
+    if is_cnv:
+        rec = np.empty((n, 3073), np.uint8)
+        rec[:, 0] = 1
+        rec[:, 1:] = imgs
+        f.write(rec.tobytes())
+    else:
+        f.write((0x803).to_bytes(4, "big") + n.to_bytes(4, "big") + (28).to_bytes(4, "big") * 2 + imgs.tobytes())
+    f.flush()
+
+
+def measure_host_paths(network, dataset, n, dev, device_index, reps=9):
+    """The reference's own entry points at a given call size: `inference_multiple(path)` on a file in the page cache (what
+    classify_cifars / classify_mnists run: /root/reference/bnn/bnn.py:306-309,370-373 -- the reference's published numbers
+    are this call on a 10 000-record test-set file) and `bnn_mi355x_inference_buffer` on a pageable host array, whole calls
+    by the wall clock (best and median of `reps`), next to the resident rate of the same images.  Classes of ALL n images
+    checked against the CPU restatement, outside the timings."""
+    import tempfile
+    import oracle_lib as ol
+    is_cnv = network.startswith("cnv")
+    isz = 3072 if is_cnv else 784
+    L = gl.load(network)
+    if L.bnn_mi355x_set_device(device_index) != 0:
+        return {"error": L.bnn_mi355x_last_error().decode()}
+    L.load_parameters(gl.param_dir(dataset, network).encode())
+    err = L.bnn_mi355x_last_error().decode()
+    if err:
+        return {"error": err}
+    imgs = np.random.default_rng(4).integers(0, 256, (n, isz), dtype=np.uint8)
+    d = torch.from_numpy(imgs).to(dev)
+    cls = torch.zeros(n, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream()
+    assert L.bnn_mi355x_reserve(n) == 0
+
+    def resident():
+        if L.bnn_mi355x_inference_device(d.data_ptr(), n, 10, cls.data_ptr(), None, None, stream.cuda_stream) != 0:
+            raise RuntimeError(L.bnn_mi355x_last_error().decode())
+        torch.cuda.synchronize()
+    for _ in range(3):
+        resident()
+    res = []
+    for _ in range(reps):
+        t = time.perf_counter()
+        resident()
+        res.append(time.perf_counter() - t)
+    usec, cnt = C.c_float(0), C.c_int(0)
+    buf, fil = [], []
+    got_b = got_f = None
+    devnull, saved = os.open(os.devnull, os.O_WRONLY), os.dup(1)
+    sys.stdout.flush()
+    os.dup2(devnull, 1)                       # the ABI prints its two lines per call, like the reference
+    try:
+        for _ in range(reps + 1):
+            t = time.perf_counter()
+            p = L.bnn_mi355x_inference_buffer(imgs.ctypes.data, n, 10, C.byref(usec), 0)
+            buf.append(time.perf_counter() - t)
+            if not p:
+                return {"error": L.bnn_mi355x_last_error().decode()}
+            got_b = np.ctypeslib.as_array(p, (n,)).copy()
+            L.free_results(p)
+        with tempfile.NamedTemporaryFile(dir="/tmp", suffix=".bin") as f:
+            write_input_file(f, imgs, is_cnv)
+            for _ in range(reps + 1):
+                t = time.perf_counter()
+                p = L.inference_multiple(f.name.encode(), 10, C.byref(cnt), C.byref(usec), 0)
+                fil.append(time.perf_counter() - t)
+                if not p or cnt.value != n:
+                    return {"error": L.bnn_mi355x_last_error().decode()}
+                got_f = np.ctypeslib.as_array(p, (n,)).copy()
+                L.free_results(p)
+    finally:
+        os.dup2(saved, 1)
+        os.close(devnull)
+        os.close(saved)
+    want = ol.Oracle(network, ol.param_dir(dataset, network)).classes_batched(imgs, 10, host_cores())
+    same = bool((got_b == want).all() and (got_f == want).all() and (cls.cpu().numpy() == want).all())
+    L.deinit()
+
+    def fig(ts):
+        ts = sorted(ts[1:])                   # (the first call sizes buffers)
+        return {"best_ms": round(ts[0] * 1e3, 4), "median_ms": round(ts[len(ts) // 2] * 1e3, 4), "value": round(n / ts[0], 1),
+                "value_median": round(n / ts[len(ts) // 2], 1), "unit": "images/s"}
+    res.sort()
+    return {"workload": "%s, %d synthetic images per call: file in the page cache -> classes (inference_multiple) / pageable host array -> "
+                        "classes (bnn_mi355x_inference_buffer); whole calls by the wall clock, %d calls each" % (network, n, reps),
+            "file_abi": fig(fil), "buffer": fig(buf),
+            "resident": {"best_ms": round(res[0] * 1e3, 4), "value": round(n / res[0], 1), "unit": "images/s",
+                         "note": "bnn_mi355x_inference_device + synchronize, the same images in HBM"},
+            "usecPerImage_reported": round(float(usec.value), 5), "classes_equal_oracle": same, "checked_images": n}
+
+
+def measure_config(network, dataset, batch, dev, device_index, steps, warmup, check=2048, cal=None):
     """One more single-GPU BASELINE config through the same device-pointer entry point: images/s over `steps`
     timed calls (inputs resident in HBM), HBM- and integer-issue fractions, and the classes of a bounded sample
     compared with the CPU restatement (outside the timed region)."""
@@ -246,7 +390,8 @@ def measure_config(network, dataset, batch, dev, device_index, steps, warmup, ch
             "unit": "images/s", "us_per_step": round(dt * 1e6, 2), "steps": steps,
             "roofline": {"bound": "hbm", "achieved": round(alg * rate / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(alg * rate / 1e9 / HBM_PEAK_GBS, 6), "algorithmic_bytes_per_image": alg},
-            "valu": {"achieved": round(rate, 1), "peak": round(ceiling, 1), "unit": "images/s per GPU", "frac": round(rate / ceiling, 4)},
+            "valu": dict({"achieved": round(rate, 1), "peak": round(ceiling, 1), "unit": "images/s per GPU", "frac": round(rate / ceiling, 4)},
+                         **valu_measured(network, rate, cal)),
             "classes_equal_oracle": same, "checked_images": k}
 
 
@@ -485,8 +630,15 @@ def main():
         dominant.update({"algorithmic_bytes_per_image": dom_alg,
                          "achieved": round(dom_alg * a.batch / (per_stage[dom] * 1e-3) / 1e9, 2), "unit": "GB/s",
                          "frac": round(dom_alg * a.batch / (per_stage[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)})
+    # what HBM really moved (the PMC passes' bytes per image x this launch) over the time of a step: "rocprof HBM GB/s against the
+    # chip's peak" in the north-star's words; `achieved` prices the path at its ALGORITHMIC bytes
+    hbm_measured = None
+    if traffic:
+        gbs = traffic / (elapsed / a.steps) / 1e9 * (a.batch / imgs_per_launch)
+        hbm_measured = {"gbs": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 5), "unit": "GB/s",
+                        "note": "roofline.traffic (stored PMC passes, scaled to the images of a step) / ms_per_step"}
     roofline = {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source,
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_source, "hbm_measured": hbm_measured,
                 "traffic_bytes_per_image_by_stage": traffic_stages,
                 "kernel": "all %d stages of one batch (dominant: %s, %.1f%% of device time)" % (
                     nst, names[dom], 100.0 * per_stage[dom] / dev_ms),
@@ -515,7 +667,16 @@ def main():
     out["valu"] = {"bound": "integer-pipe issue (v_xor/v_bitop3 + v_bcnt pairs, v_dot4c)", "achieved": round(per_gpu, 1),
                    "peak": round(ceiling, 1), "unit": "images/s per GPU", "frac": round(per_gpu / ceiling, 4),
                    "simd_cycles_per_image_floor": round(floor_cyc, 1), "clock_ghz": CLK_HZ / 1e9,
-                   "note": "the path is bound by integer VALU issue, not HBM: this is the meaningful ceiling (DESIGN.md 5)"}
+                   "pair_cycles": PAIR_CYC_OF[a.network[3:]],
+                   "note": "the path is bound by integer VALU issue, not HBM: this is the meaningful ceiling (DESIGN.md 5).  `peak` / `frac` use the "
+                           "constants every round has quoted (round-1 microbenchmarks on another box); `peak_measured` / `frac_measured` the "
+                           "pair rate and clock tools/issue_probe.hip measured on this device in this run (valu.calibration)"}
+    # ---- the issue ceiling measured on this device, in this run, outside the timed region
+    cal = None
+    if world == 1 and not a.no_extras:
+        cal = calibrate_issue()
+        out["valu"]["calibration"] = cal
+        out["valu"].update(valu_measured(a.network, per_gpu, cal))
 
     # ---- secondary figures (single GPU only, outside the timed region of `value`)
     if world == 1 and not a.no_extras:
@@ -614,13 +775,43 @@ def main():
     # the timed region of `value`: a few ms of GPU time each, classes of a sample checked against the oracle
     if world == 1 and not a.no_extras and a.network == "cnvW1A1":
         out["other_configs"] = {
-            "lfcW1A1_10000": measure_config("lfcW1A1", "mnist", 10000, dev, local_rank, 300, 20),
-            "lfcW1A1_131072": measure_config("lfcW1A1", "mnist", 131072, dev, local_rank, 40, 5),
-            "cnvW2A2_131072": measure_config("cnvW2A2", "cifar10", 131072, dev, local_rank, 8, 2),
+            "lfcW1A1_10000": measure_config("lfcW1A1", "mnist", 10000, dev, local_rank, 300, 20, cal=cal),
+            "lfcW1A1_131072": measure_config("lfcW1A1", "mnist", 131072, dev, local_rank, 40, 5, cal=cal),
+            "cnvW2A2_131072": measure_config("cnvW2A2", "cifar10", 131072, dev, local_rank, 8, 2, cal=cal),
             # the two W1A2 overlays, same entry point
-            "cnvW1A2_131072": measure_config("cnvW1A2", "cifar10", 131072, dev, local_rank, 8, 2),
-            "lfcW1A2_131072": measure_config("lfcW1A2", "mnist", 131072, dev, local_rank, 40, 5),
+            "cnvW1A2_131072": measure_config("cnvW1A2", "cifar10", 131072, dev, local_rank, 8, 2, cal=cal),
+            "lfcW1A2_131072": measure_config("lfcW1A2", "mnist", 131072, dev, local_rank, 40, 5, cal=cal),
         }
+        for key, st in (("cnvW2A2_131072", "cnvW2A2"), ("cnvW1A2_131072", "cnvW1A2")):   # HBM traffic of these configs (stored PMC passes)
+            try:
+                t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(st)
+                if t:
+                    per = t["fetch_bytes_per_image_x2"] + t["write_bytes_per_image"]
+                    r_ = out["other_configs"][key]["roofline"]
+                    r_["traffic"] = int(per * 131072)
+                    r_["traffic_source"] = "profiles/traffic.json (%s), scaled to this launch; not re-measured in this run" % t.get("source", "profiles/")
+                    r_["hbm_measured"] = {"gbs": round(per * out["other_configs"][key]["value"] / 1e9, 1), "unit": "GB/s",
+                                          "frac": round(per * out["other_configs"][key]["value"] / 1e9 / HBM_PEAK_GBS, 5)}
+            except Exception:
+                pass
+        # the reference's own entry points at the reference's own call size (a 10 000-record test-set file: the call behind every
+        # number the reference publishes), and the LFC host paths at the headline batch
+        hp = measure_host_paths("cnvW1A1", "cifar10", 10000, dev, local_rank)
+        out["other_configs"]["cnvW1A1_10000_file_abi"] = dict(hp.get("file_abi", {}), resident=hp.get("resident"), workload=hp.get("workload"),
+                                                              classes_equal_oracle=hp.get("classes_equal_oracle"), checked_images=hp.get("checked_images"),
+                                                              **({"error": hp["error"]} if "error" in hp else {}))
+        out["other_configs"]["cnvW1A1_10000_buffer"] = dict(hp.get("buffer", {}), resident=hp.get("resident"), workload=hp.get("workload"),
+                                                            classes_equal_oracle=hp.get("classes_equal_oracle"), checked_images=hp.get("checked_images"))
+        hp = measure_host_paths("lfcW1A1", "mnist", 10000, dev, local_rank)
+        out["other_configs"]["lfcW1A1_10000_file_abi"] = dict(hp.get("file_abi", {}), buffer=hp.get("buffer"), resident=hp.get("resident"),
+                                                              workload=hp.get("workload"), classes_equal_oracle=hp.get("classes_equal_oracle"),
+                                                              checked_images=hp.get("checked_images"), **({"error": hp["error"]} if "error" in hp else {}))
+        hp = measure_host_paths("lfcW1A1", "mnist", 131072, dev, local_rank, reps=7)
+        out["other_configs"]["lfcW1A1_131072_host_paths"] = dict(file_abi=hp.get("file_abi"), buffer=hp.get("buffer"), resident=hp.get("resident"),
+                                                                 workload=hp.get("workload"), classes_equal_oracle=hp.get("classes_equal_oracle"),
+                                                                 checked_images=hp.get("checked_images"),
+                                                                 note="host paths binarise on the host like the reference (104 B per image over PCIe)",
+                                                                 **({"error": hp["error"]} if "error" in hp else {}))
         if not all(v.get("classes_equal_oracle") for v in out["other_configs"].values()):
             print(json.dumps(out))
             sys.exit("PARITY FAILURE in other_configs")
