@@ -579,11 +579,11 @@ struct ResultSlots {
   uint64_t *h_words = nullptr, *d_words = nullptr;
   int16_t *h_scores = nullptr, *d_scores = nullptr;
 };
-ResultSlots mapped_results(int n, bool scores) {
+ResultSlots mapped_results(int n, bool scores, bool direct = false) {
   Runtime &r = rt();
   ResultSlots m;
-  static const bool off = std::getenv("BNN_MI355X_NO_MAPPED_RESULTS") != nullptr;  // A/B
-  if (off || n > kMappedResMax || (scores && n > kMappedScoresMax) || ensure_io()) return m;
+  static const bool off = std::getenv("BNN_MI355X_NO_MAPPED_RESULTS") != nullptr;  // A/B of the chunked calls (a direct call has no other way)
+  if ((off && !direct) || n > kMappedResMax || (scores && n > kMappedScoresMax) || ensure_io()) return m;
   m.h_classes = reinterpret_cast<int32_t *>(r.h_io + kIoClassesOff);
   m.d_classes = reinterpret_cast<int32_t *>(r.d_io + kIoClassesOff);
   m.h_words = reinterpret_cast<uint64_t *>(r.h_io + kIoWordsOff);
@@ -1089,7 +1089,7 @@ int warm_up() {
   // the pinned I/O block of the direct calls, and one image through it
   if (ensure_io()) return -1;
   {
-    const ResultSlots m = mapped_results(1, r.spec.is_cnv);
+    const ResultSlots m = mapped_results(1, r.spec.is_cnv, true);
     if (m.d_classes && enqueue(r.spec.is_cnv ? r.d_io + 16 : r.d_io, 1, 10, m.d_classes, m.d_scores, m.d_words, r.stream, r.io_t0, r.io_t1, 0, true, !r.spec.is_cnv))
       return -1;
   }
@@ -1379,7 +1379,7 @@ int infer_direct(const Source &src, int n, int ncls, int32_t *classes, int16_t *
     binarize_pack(src.mem, (size_t)n, reinterpret_cast<uint64_t *>(r.h_io));
   }
   const bool want_scores = scores && r.spec.is_cnv;
-  const ResultSlots m = mapped_results(n, want_scores);
+  const ResultSlots m = mapped_results(n, want_scores, true);
   if (!m.d_classes) return fail("pinned I/O block unavailable");
   DrainOnFailure drain;
   trace().mark("input_placed");
