@@ -154,14 +154,23 @@ int bnn_mi355x_inference_device(const void *d_images, int n_images, int number_c
                                 int16_t *d_scores, uint64_t *d_words, void *hip_stream);
 int bnn_mi355x_reserve(int max_images);
 
-/* How the entry points that take HOST data cut a call of n images into chunks whose transfer overlaps the
- * previous chunk's stages: small chunks first (the first transfer is what nothing overlaps), each 1.5 times the one
- * before, up to 16 384 images (the LFC nets: 32 768); from_file != 0: inference_multiple(path), which starts at 4 096 images,
- * from_file == 0: inference_buffer / inference_raw, which start at 2 048 (MNIST images: four times as many).  A call of three
- * or more chunks runs them alternately on two internal streams ("compute lanes"), each with its own activation workspace;
- * usecPerImage is then the union of the chunks' device intervals over the images.  Writes the chunk
- * boundaries base[0] = 0 < base[1] < ... < base[k] = n (at most cap of them) and returns k + 1.  Host only; results never
- * depend on the plan (tests/test_gpu_parity.py walks its edges). */
+/* How the entry points that take HOST data (inference_multiple, inference_buffer, inference_raw) move it:
+ *  - a single CIFAR image, or up to 1 024 MNIST images: no transfer at all -- the image (LFC: binarised by the calling thread)
+ *    is placed in pinned memory the GPU addresses, the one-launch kernels read it over the link and write their results into
+ *    pinned memory; one launch, one wait.
+ *  - the LFC networks otherwise: worker threads binarise (bnn_mi355x_binarize_pack) into pinned memory, 104 bytes per image
+ *    cross the link; chunks of 8 192 images first, doubling up to 32 768.
+ *  - the CNV networks otherwise: chunks whose transfer overlaps the previous chunks' stages: 512 images first (the first
+ *    transfer is what nothing overlaps), doubling up to 4 096, then growing by half up to 16 384; a call below 32 768 images
+ *    ramps down again at its end (512 last).  A file is read by worker threads straight into a ring of pinned pieces, the label
+ *    byte of every record dropped on the way (preadv); a host buffer goes through the runtime's pageable path, its copies
+ *    issued by a helper thread while the calling thread enqueues stages.
+ * A call of three or more chunks runs them alternately on two internal streams ("compute lanes"), each with its own activation
+ * workspace; usecPerImage is then the union of the chunks' device intervals over the images.  Results of calls up to 32 768
+ * images are written by the last stage into pinned memory, larger ones come back in one transfer at the end.
+ * chunk_plan writes the chunk boundaries base[0] = 0 < base[1] < ... < base[k] = n (at most cap of them) and returns k + 1
+ * (from_file is accepted for compatibility: both entry points use the same plan since round 4).  Host only; results never
+ * depend on the plan (tests/test_gpu_parity.py and tests/test_gpu_host_paths.py walk its edges). */
 int bnn_mi355x_chunk_plan(int n_images, int from_file, int *bases, int cap);
 
 /* Fault campaigns: fix the seed of the fault planner (0 = std::random_device like the

@@ -167,7 +167,7 @@ def test_campaign_on_gpu_replayed_in_oracle(network, dataset, target, word_size,
 
 @pytest.mark.gpu
 def test_campaign_over_a_multi_chunk_file(tmp_path):
-    """70 000 MNIST images: the resident load streams three 32 768-image chunks, runs of images between
+    """70 000 MNIST images: the resident load streams the file in several chunks (pageable host chunks, raw pixels), runs of images between
     fault times cross chunk borders; replayed in the oracle like the small campaigns"""
     network, dataset, n, flips = "lfcW1A1", "mnist", 70000, 40
     L = gl.load(network)

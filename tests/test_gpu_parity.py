@@ -362,9 +362,9 @@ def test_abi_edge_behaviour(tmp_path):
 @pytest.mark.parametrize("network,dataset,n", [("cnvW1A1", "cifar10", 70001), ("cnvW2A2", "cifar10", 33000),
                                                ("lfcW1A1", "mnist", 100003), ("lfcW1A2", "mnist", 40000)])
 def test_file_abi_streams_multi_chunk_files(network, dataset, n, tmp_path):
-    """inference_multiple on files of several 32768-image chunks (the records go to HBM as they lie on disk,
-    reader threads one chunk ahead, labels stripped by a kernel): same classes as the in-memory entry
-    point, detail scores included; inference() classifies the first record only"""
+    """inference_multiple on files of many chunks (512 ... 16 384 records; the LFC nets: binarised on the host, 8 192 ...
+    32 768 images): reader threads fill a ring of pinned pieces, dropping the label byte of every record on the way; same
+    classes as the in-memory entry point, detail scores included; inference() classifies the first record only"""
     net = gpu_net(network, dataset)
     L = net.L
     cnv = network.startswith("cnv")
