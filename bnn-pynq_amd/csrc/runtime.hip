@@ -1581,8 +1581,14 @@ int *classify_with(Infer infer, int n, int ncls, int enable_detail) {
     result = new (std::nothrow) int[(size_t)(n > 0 ? n : 1)];
     if (!result) { fail("out of memory"); return nullptr; }
     if (infer(result, nullptr, nullptr, nullptr)) { delete[] result; return nullptr; }
+  } else if (ncls <= 47) {
+    // the LFC libraries ignore enable_detail (lfcW1A1/sw/main_python.cpp:135-156).  Up to 47 classes the reference's
+    // (unsigned) log2((double) word) IS the index of the highest set bit (lfc_class_batched above), which the last stage
+    // computes on the device: the classes come back as they are, no pass over 131 072 words on the host after the wait
+    result = new (std::nothrow) int[(size_t)(n > 0 ? n : 1)];
+    if (!result) { fail("out of memory"); return nullptr; }
+    if (infer(result, nullptr, nullptr, nullptr)) { delete[] result; return nullptr; }
   } else {
-    // the LFC libraries ignore enable_detail (lfcW1A1/sw/main_python.cpp:135-156)
     const uint64_t *w = nullptr;  // the raw output words, where the call left them (pinned memory)
     if (infer(nullptr, nullptr, nullptr, &w)) return nullptr;
     result = new (std::nothrow) int[(size_t)(n > 0 ? n : 1)];

@@ -41,14 +41,19 @@ for net, ds in (("cnvW1A1", "cifar10"), ("cnvW1A2", "cifar10"), ("cnvW2A2", "cif
     print(net, "ok:", len(sizes), "sizes", flush=True)
 # the file entry point either side of the size from which worker threads feed a ring of pinned pieces (24 MB), odd counts
 import ctypes as C, tempfile
-for net, ds, rec, nn in (("cnvW1A1", "cifar10", 3073, [7809, 7811, 8200, 9999, 12345, 33001, 70003]), ("lfcW1A1", "mnist", 784, [30000, 32101, 40001, 100003])) if only in ("all", "files") else ():
+# (round 4: the ring from 2 MB = 682 records on, pieces of 85 / 170 records, readers' preadv batches of 512 records, a two-sided
+# chunk plan below 32 768 images; the LFC nets direct up to 1 024 images, binarised by worker threads beyond, chunks of 8 192 ...)
+extra_c = [1, 2, 85, 86, 170, 171, 511, 512, 513, 681, 682, 683, 1023, 1024, 1025, 1537, 2047, 4097] + [int(x) for x in rng.integers(600, 40000, 10)]
+extra_l = [1, 2, 255, 256, 257, 1023, 1024, 1025, 2049, 8191, 8192, 8193, 16383, 16384, 16385] + [int(x) for x in rng.integers(900, 140000, 8)]
+for net, ds, rec, nn in (("cnvW1A1", "cifar10", 3073, [7809, 7811, 8200, 9999, 12345, 33001, 70003] + extra_c), ("cnvW2A2", "cifar10", 3073, extra_c[-6:]),
+                         ("lfcW1A1", "mnist", 784, [30000, 32101, 40001, 100003] + extra_l), ("lfcW1A2", "mnist", 784, extra_l[-10:])) if only in ("all", "files") else ():
     N = gl.Net(net, ds)
     o = ol.Oracle(net, ol.param_dir(ds, net))
     for n in nn:
         imgs = rng.integers(0, 256, (n, N.isz), dtype=np.uint8)
         with tempfile.NamedTemporaryFile(dir="/tmp", suffix=".bin") as f:
             if rec == 3073:
-                r = np.empty((n, 3073), np.uint8); r[:, 0] = 7; r[:, 1:] = imgs; f.write(r.tobytes())
+                r = np.empty((n, 3073), np.uint8); r[:, 0] = rng.integers(0, 256, n); r[:, 1:] = imgs; f.write(r.tobytes())
             else:
                 f.write((0x803).to_bytes(4, "big") + n.to_bytes(4, "big") + (28).to_bytes(4, "big") * 2 + imgs.tobytes())
             f.flush()
