@@ -107,10 +107,12 @@ std::vector<int> plan_chunks(int n, bool single, bool /*from_file*/) {
   // 10 000 images as ONE chunk 62 M/s against 53 M/s in three; profiles/r04_small_call_plan_sweep.txt).
   const bool cnv = net_spec(BNN_NETWORK).is_cnv;
   const int scale = cnv ? 1 : 4;
-  // ... and a CNV call below 32 768 images ramps DOWN as well: at that size the bytes arrive about as fast as small chunks'
-  // stages consume them, and what follows the last byte is the last chunk's stages (10 000 images from a buffer 1.146 ->
-  // 1.094 ms, from a file 1.33 -> 1.275; 131 072 images lose 3 % to the small chunks at the end and keep the one-sided ramp)
-  int head = cnv ? kHeadChunk : 8192, tail = (cnv && n < 32768) ? kHeadChunk : 0, big = cnv ? kHostChunkCnv : kHostChunk, growth = cnv ? 0 : 200;
+  // ... and a CNV call of 8 192 ... 32 767 images ramps DOWN as well: at that size the bytes arrive about as fast as small
+  // chunks' stages consume them, and what follows the last byte is the last chunk's stages.  Interleaved A/B
+  // (tools/plan_ab.py, profiles/r04_plan_ab_interleaved.txt, medians of 20-40 rounds): 10 000 images from a file 1.243 ->
+  // 1.228 ms, from a buffer 1.137 -> 1.132; 20 000 images 2.297 -> 2.251 / 2.065 -> 2.059; 5 000 images LOSE 3-4 % to the two
+  // extra chunks, 131 072 images 3 %: those keep the one-sided ramp.
+  int head = cnv ? kHeadChunk : 8192, tail = (cnv && n >= 8192 && n < 32768) ? kHeadChunk : 0, big = cnv ? kHostChunkCnv : kHostChunk, growth = cnv ? 0 : 200;
   if (const char *e = std::getenv("BNN_MI355X_CHUNKS")) {
     int h = 0, t = 0, b = 0, g = 150;
     const int got = std::sscanf(e, "%d:%d:%d:%d", &h, &t, &b, &g);

@@ -161,8 +161,8 @@ int bnn_mi355x_reserve(int max_images);
  *  - the LFC networks otherwise: worker threads binarise (bnn_mi355x_binarize_pack) into pinned memory, 104 bytes per image
  *    cross the link; chunks of 8 192 images first, doubling up to 32 768.
  *  - the CNV networks otherwise: chunks whose transfer overlaps the previous chunks' stages: 512 images first (the first
- *    transfer is what nothing overlaps), doubling up to 4 096, then growing by half up to 16 384; a call below 32 768 images
- *    ramps down again at its end (512 last).  A file is read by worker threads straight into a ring of pinned pieces, the label
+ *    transfer is what nothing overlaps), doubling up to 4 096, then growing by half up to 16 384; a call of 8 192 ... 32 767
+ *    images ramps down again at its end (512 last).  A file is read by worker threads straight into a ring of pinned pieces, the label
  *    byte of every record dropped on the way (preadv); a host buffer goes through the runtime's pageable path, its copies
  *    issued by a helper thread while the calling thread enqueues stages.
  * A call of three or more chunks runs them alternately on two internal streams ("compute lanes"), each with its own activation

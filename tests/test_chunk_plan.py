@@ -17,8 +17,8 @@ def test_chunk_plan_properties():
     """the plan the host-data entry points cut a call by: covers [0, n) in order, no chunk above 16 384 (CNV) / 32 768 (LFC) images, small
     chunks first (the first transfer is what nothing overlaps: 512 CIFAR images; the LFC nets, whose host paths ship binarised
     words: 8 192), doubling up to 4 096 (LFC: all the way) and growing by half from there on so that a chunk's transfer fits behind
-    the previous chunk's stages; a CNV call below 32 768 images ramps down again at its end (what follows the last byte is the
-    last chunk's stages), larger calls and the LFC nets do not"""
+    the previous chunk's stages; a CNV call of 8 192 ... 32 767 images ramps down again at its end (what follows the last byte is
+    the last chunk's stages), smaller and larger calls and the LFC nets do not"""
     for network, scale, big, head in (("cnvW1A1", 1, 16384, 512), ("lfcW1A1", 4, 32768, 8192)):
         L = gl.load(network)
         for from_file in (0, 1):
@@ -32,7 +32,7 @@ def test_chunk_plan_properties():
                     assert k == 2
                     continue
                 assert sizes[0] == head or (sizes[0] > head and len(sizes) == 2)     # (a tiny middle chunk joins the first)
-                two_sided = scale == 1 and n < 32768
+                two_sided = scale == 1 and 8192 <= n < 32768
                 if two_sided:
                     def ramp(seq):                                    # how far `seq` follows the growth rule from `head`
                         want, k = head, 0
