@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "faults.h"
+#include "pack_inputs.h"
 #include "packed_params.h"
 #include "resample.h"
 #include "topology.h"
@@ -52,6 +53,30 @@ int main(int argc, char **argv) {
     if (validate_blob(net, bad.data(), bad.size()).empty()) return 1;
     if (validate_blob(net, blob.data(), blob.size() / 2).empty()) return 1;
     if (validate_blob(net, blob.data(), 8).empty()) return 1;
+  }
+  // binarizeAndPack on the host (what the LFC host paths run on their worker threads): exact-size heap buffers at every
+  // byte alignment -- a read past the 784th pixel of the last image or a write past its 13th word is a finding --, both
+  // forms against the definition
+  {
+    for (size_t n : {(size_t)0, (size_t)1, (size_t)2, (size_t)7, (size_t)80, (size_t)81}) {
+      for (size_t soff = 0; soff < 4; soff++)
+        for (size_t doff : {(size_t)0, (size_t)8, (size_t)3}) {
+          std::vector<uint8_t> src(soff + n * kLfcPixels + (n == 0)), dst(doff + n * kLfcWords * 8 + (n == 0)), dst2(dst.size());  // (n = 0: a non-null pointer to nothing)
+          for (size_t i = 0; i < src.size(); i++) src[i] = (uint8_t)((i * 131 + (i >> 3) * 29 + soff) & 0xFF);
+          binarize_pack(src.data() + soff, n, reinterpret_cast<uint64_t *>(dst.data() + doff));
+          binarize_pack_portable(src.data() + soff, n, reinterpret_cast<uint64_t *>(dst2.data() + doff));
+          if (std::memcmp(dst.data() + doff, dst2.data() + doff, n * kLfcWords * 8) != 0) return 1;
+          for (size_t i = 0; i < n; i++)
+            for (int b = 0; b < kLfcWords * 64; b++) {
+              uint64_t w;
+              std::memcpy(&w, dst.data() + doff + (i * kLfcWords + b / 64) * 8, 8);
+              const int want = b < kLfcPixels ? (src[soff + i * kLfcPixels + b] >= 128) : 0;
+              if ((int)((w >> (b % 64)) & 1) != want) return 1;
+            }
+          checked += (long)n;
+        }
+    }
+    std::printf("binarize_pack: %s form\n", binarize_pack_isa());
   }
   // a missing directory is an error string, not a crash
   {
