@@ -784,7 +784,8 @@ def main():
             "cnvW1A2_131072": measure_config("cnvW1A2", "cifar10", 131072, dev, local_rank, 8, 2, cal=cal),
             "lfcW1A2_131072": measure_config("lfcW1A2", "mnist", 131072, dev, local_rank, 40, 5, cal=cal),
         }
-        for key, st in (("cnvW2A2_131072", "cnvW2A2"), ("cnvW1A2_131072", "cnvW1A2")):   # HBM traffic of these configs (stored PMC passes)
+        for key, st in (("cnvW2A2_131072", "cnvW2A2"), ("cnvW1A2_131072", "cnvW1A2"), ("lfcW1A1_131072", "lfcW1A1"),
+                        ("lfcW1A2_131072", "lfcW1A2")):                                   # HBM traffic of these configs (stored PMC passes)
             try:
                 t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(st)
                 if t:
