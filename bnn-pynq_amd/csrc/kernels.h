@@ -24,6 +24,10 @@ struct CnvLaunch {
   hipEvent_t *events;         // optional: kCnvStages+1 events, recorded around every stage
   int last_stage;             // run stages 0..last_stage only (debug / per-layer tests); kCnvStages-1 = all
   hipEvent_t t0, t1;          // optional (both or neither): the batch's device time is t0 -> t1 (see LfcLaunch)
+  // optional, n == 1 only (one image: the last launch is one block): a word in pinned host memory that the last kernel
+  // sets to done_seq behind its results -- the host spins on it; no t0 / t1 packets are queued then
+  unsigned *done_flag;
+  unsigned done_seq;
 };
 
 struct LfcLaunch {
@@ -47,6 +51,8 @@ struct LfcLaunch {
   // such events of DIFFERENT dispatches is not an interval a multi-chunk call could place its chunks by; those get
   // ordinary recorded events around the launch.
   bool t_dispatch;
+  unsigned *done_flag;        // as CnvLaunch::done_flag (n == 1: the one-block form of k_lfc_fused*)
+  unsigned done_seq;
 };
 
 // layer-0 MFMA table (packed_params.h): the tile-form operands sit behind the pixel-form ones

@@ -75,6 +75,15 @@ __device__ __forceinline__ BlockMap map_block(int groups, int n_items) {
 
 __device__ __forceinline__ int pc64(uint64_t x) { return __builtin_popcountll(x); }
 
+// A single-image call may ask for a completion mark in pinned host memory (runtime.hip, infer_direct): the wave that
+// wrote the results drains its stores (system scope) and then stores `seq` -- the host spins on that word instead of
+// waiting on the runtime.  Only meaningful for one-block launches.
+__device__ __forceinline__ void mark_done(unsigned *done, unsigned seq, int lane) {
+  if (!done) return;
+  __threadfence_system();
+  if (lane == 0) *reinterpret_cast<volatile unsigned *>(done) = seq;
+}
+
 // ---------------------------------------------------------------------------
 // activation outputs
 // ---------------------------------------------------------------------------
@@ -1266,7 +1275,8 @@ __device__ __forceinline__ int xnor_row(const uint32_t *__restrict__ rows, int n
 __global__ __launch_bounds__(512) void k_cnv_tail(const uint64_t *__restrict__ in, int16_t *__restrict__ scores,
                                                    int32_t *__restrict__ classes, const uint32_t *__restrict__ r4,
                                                    const uint32_t *__restrict__ r5, const uint32_t *__restrict__ r6,
-                                                   const uint32_t *__restrict__ r7, const uint32_t *__restrict__ r8, int number_class) {
+                                                   const uint32_t *__restrict__ r7, const uint32_t *__restrict__ r8, int number_class,
+                                                   unsigned *done, unsigned done_seq) {
   __shared__ uint64_t x3[50], x4[36], x5[4], x6[8], x7[8];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, img = blockIdx.x;
   if (t < 50) x3[t] = in[(size_t)img * 50 + t];
@@ -1326,6 +1336,7 @@ __global__ __launch_bounds__(512) void k_cnv_tail(const uint64_t *__restrict__ i
       for (int off = 32; off >= 1; off >>= 1) key = max(key, __shfl_xor(key, off, 64));
       if (lane == 0) classes[img] = key < 0 ? 0 : 63 - (key & 63);
     }
+    mark_done(done, done_seq, lane);
   }
 }
 
@@ -1359,7 +1370,8 @@ template <int ARITH>
 __global__ __launch_bounds__(512) void k_cnv_tail_a2(const uint64_t *__restrict__ in, int16_t *__restrict__ scores,
                                                       int32_t *__restrict__ classes, const uint32_t *__restrict__ r4,
                                                       const uint32_t *__restrict__ r5, const uint32_t *__restrict__ r6,
-                                                      const uint32_t *__restrict__ r7, const uint32_t *__restrict__ r8, int number_class) {
+                                                      const uint32_t *__restrict__ r7, const uint32_t *__restrict__ r8, int number_class,
+                                                      unsigned *done, unsigned done_seq) {
   // [plane 0 = sign, 1 = non-zero][word]
   __shared__ uint64_t x3[2][50], x4[2][36], x5[2][4], x6[2][8], x7[2][8];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, img = blockIdx.x;
@@ -1428,6 +1440,7 @@ __global__ __launch_bounds__(512) void k_cnv_tail_a2(const uint64_t *__restrict_
       for (int off = 32; off >= 1; off >>= 1) key = max(key, __shfl_xor(key, off, 64));
       if (lane == 0) classes[img] = key < 0 ? 0 : 63 - (key & 63);
     }
+    mark_done(done, done_seq, lane);
   }
 }
 
@@ -1496,7 +1509,7 @@ template <int IPB, bool PACKED = false>
 __global__ __launch_bounds__(1024) void k_lfc_fused_a2(const uint8_t *__restrict__ imgs, uint64_t *__restrict__ words,
                                                         int32_t *__restrict__ classes, const uint32_t *__restrict__ r0,
                                                         const uint32_t *__restrict__ r1, const uint32_t *__restrict__ r2,
-                                                        const uint32_t *__restrict__ r3, int n_images, int number_class) {
+                                                        const uint32_t *__restrict__ r3, int n_images, int number_class, unsigned *done, unsigned done_seq) {
   __shared__ uint64_t in0[IPB][16];        // binarised input
   __shared__ uint64_t sg[2][IPB][16], nzp[2][IPB][16];  // ping-pong (sign, non-zero) planes
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, img0 = blockIdx.x * IPB;
@@ -1561,6 +1574,7 @@ __global__ __launch_bounds__(1024) void k_lfc_fused_a2(const uint8_t *__restrict
         }
       }
     }
+    mark_done(done, done_seq, lane);
   }
 }
 
@@ -1586,7 +1600,7 @@ template <int IPB, bool PACKED = false>
 __global__ __launch_bounds__(1024) void k_lfc_fused(const uint8_t *__restrict__ imgs, uint64_t *__restrict__ words,
                                                      int32_t *__restrict__ classes, const uint32_t *__restrict__ r0,
                                                      const uint32_t *__restrict__ r1, const uint32_t *__restrict__ r2,
-                                                     const uint32_t *__restrict__ r3, int n_images, int number_class) {
+                                                     const uint32_t *__restrict__ r3, int n_images, int number_class, unsigned *done, unsigned done_seq) {
   __shared__ uint64_t act[2][IPB][16];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, img0 = blockIdx.x * IPB;
   // the layers are a dependent chain, their weight traffic need not be: the row of layer L+1 is
@@ -1654,6 +1668,7 @@ __global__ __launch_bounds__(1024) void k_lfc_fused(const uint8_t *__restrict__ 
         }
       }
     }
+    mark_done(done, done_seq, lane);
   }
 }
 
@@ -2015,7 +2030,7 @@ void run_cnv_t(const CnvLaunch &a) {
     if (n <= kCnvTailMax && !a.events && a.last_stage >= kCnvStages - 1) {
       // small batch: layers 4..8 as one launch (no per-stage events there: there are no stages)
       hipLaunchKernelGGL(k_cnv_tail, dim3((unsigned)n), dim3(512), 0, s, B64, a.scores, a.classes, a.rows[4], a.rows[5], a.rows[6],
-                         a.rows[7], a.rows[8], a.number_class);
+                         a.rows[7], a.rows[8], a.number_class, n == 1 ? a.done_flag : nullptr, a.done_seq);
       return;
     }
     if (a.last_stage >= 4) BNN_STAGE((k_vec_x<18, true, 2, 5>), (k_vec_x<18, true, 2, 5, 8>), n * 9, 8, B64, A, a.rows[4]);
@@ -2046,7 +2061,7 @@ void run_cnv_t(const CnvLaunch &a) {
     if constexpr (!TWO) {  // (the -2-aware variant of this kernel would spill: such runs take the staged layers)
       if (n <= kCnvTailMax && !a.events && a.last_stage >= kCnvStages - 1) {
         hipLaunchKernelGGL((k_cnv_tail_a2<ARITH>), dim3((unsigned)n), dim3(512), 0, s, B64, a.scores, a.classes, a.rows[4], a.rows[5],
-                           a.rows[6], a.rows[7], a.rows[8], a.number_class);
+                           a.rows[6], a.rows[7], a.rows[8], a.number_class, n == 1 ? a.done_flag : nullptr, a.done_seq);
         return;
       }
     }
@@ -2127,7 +2142,8 @@ void l1_mfma_table(const uint32_t *rows, uint8_t *dst) {
 
 hipError_t run_cnv(NetId net, const CnvLaunch &a) {
   if (a.n <= 0) return hipSuccess;
-  if (a.t0) (void)hipEventRecord(a.t0, a.stream);
+  const bool marked = a.done_flag && a.n == 1;  // (the call is timed and waited for by the completion mark: no event packets around it)
+  if (a.t0 && !marked) (void)hipEventRecord(a.t0, a.stream);
   switch (net) {
     case NET_CNVW1A1: run_cnv_t<AR_XNOR, false>(a); break;
     case NET_CNVW1A2: run_cnv_t<AR_TB, true>(a); break;
@@ -2137,7 +2153,7 @@ hipError_t run_cnv(NetId net, const CnvLaunch &a) {
       break;
     default: return hipErrorInvalidValue;
   }
-  if (a.t1) (void)hipEventRecord(a.t1, a.stream);
+  if (a.t1 && !marked) (void)hipEventRecord(a.t1, a.stream);
   return hipGetLastError();
 }
 
@@ -2155,14 +2171,15 @@ hipError_t run_lfc(NetId net, const LfcLaunch &a) {
     const dim3 g((unsigned)((n + ipb - 1) / ipb)), b(1024);
 #define BNN_FUSED_P(K, I, P)                                                                                                              \
   do {                                                                                                                                    \
-    if (a.t0 && a.t_dispatch) {                                                                                                           \
+    unsigned *const done_ = (n == 1) ? a.done_flag : nullptr; /* (a one-block launch: the completion mark is meaningful) */            \
+    if (a.t0 && a.t_dispatch && !done_) {                                                                                                 \
       hipExtLaunchKernelGGL((K<I, P>), g, b, 0, s, a.t0, a.t1, 0, a.images, a.words, a.classes, a.rows[0], a.rows[1], a.rows[2],          \
-                            a.rows[3], (int)n, a.number_class);                                                                           \
+                            a.rows[3], (int)n, a.number_class, done_, a.done_seq);                                                        \
     } else {                                                                                                                              \
-      if (a.t0) (void)hipEventRecord(a.t0, s);                                                                                            \
+      if (a.t0 && !done_) (void)hipEventRecord(a.t0, s);                                                                                  \
       hipLaunchKernelGGL((K<I, P>), g, b, 0, s, a.images, a.words, a.classes, a.rows[0], a.rows[1], a.rows[2], a.rows[3], (int)n,         \
-                         a.number_class);                                                                                                 \
-      if (a.t1) (void)hipEventRecord(a.t1, s);                                                                                            \
+                         a.number_class, done_, a.done_seq);                                                                              \
+      if (a.t1 && !done_) (void)hipEventRecord(a.t1, s);                                                                                  \
     }                                                                                                                                     \
   } while (0)
 #define BNN_FUSED(K, I)                      \

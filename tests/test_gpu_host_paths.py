@@ -115,14 +115,46 @@ print("switch-ok")
 """
 
 
-@pytest.mark.parametrize("knob", ["BNN_MI355X_NO_HOST_PACK", "BNN_MI355X_NO_DIRECT", "BNN_MI355X_NO_COPIER", "BNN_MI355X_NO_MAPPED_RESULTS",
-                                  "BNN_MI355X_NO_FEEDER"])
+@pytest.mark.parametrize("knob", ["BNN_MI355X_NO_HOST_PACK=1", "BNN_MI355X_NO_DIRECT=1", "BNN_MI355X_NO_COPIER=1", "BNN_MI355X_NO_MAPPED_RESULTS=1",
+                                  "BNN_MI355X_NO_FEEDER=1", "BNN_MI355X_DIRECT_TIMING=host"])
 def test_host_path_switches_change_nothing_but_the_route(knob, tmp_path):
     """the A/B switches of the round-4 host paths (raw pixels to HBM instead of host-binarised words; no direct small calls; copies
-    and launches on one thread; results through HBM and a copy; no pinned ring): same bits either way"""
+    and launches on one thread; results through HBM and a copy; no pinned ring; single images timed by the host and waited for
+    on a completion word in pinned memory instead of events): same bits either way"""
     code = SWITCH_CODE % {"tests": os.path.join(gl.ROOT, "tests"), "pkg": os.path.join(gl.ROOT, "bnn-pynq_amd"), "dir": str(tmp_path)}
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{knob: "1"}), capture_output=True, text=True, timeout=900)
+    k, v = knob.split("=")
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **{k: v}), capture_output=True, text=True, timeout=900)
     assert "switch-ok" in out.stdout, knob + out.stdout[-1500:] + out.stderr[-3000:]
+
+
+def test_single_images_timed_by_the_host(tmp_path):
+    """BNN_MI355X_DIRECT_TIMING=host: inference(path) of every network with the completion word instead of events -- recorded
+    fixtures (deer -> 4 with its recorded scores, 3.image -> 3), usecPerImage positive and below the call's wall time, raw
+    scores of a random image through the host-buffer entry point"""
+    code = """
+import sys, os, time, ctypes as C, numpy as np
+sys.path[:0] = [%r, %r]
+import gpu_lib as gl, oracle_lib as ol
+G = ol.GOLDEN
+for network, dataset, f, want in (("cnvW1A1", "cifar10", "deer.cifar", 4), ("cnvW1A2", "cifar10", "deer.cifar", 4), ("cnvW2A2", "cifar10", "deer.cifar", 4),
+                                  ("lfcW1A1", "mnist", "3.image-idx3-ubyte", 3), ("lfcW1A2", "mnist", "3.image-idx3-ubyte", 3)):
+    net = gl.Net(network, dataset)
+    res, usec = (C.c_int * 64)(), C.c_float(0)
+    for rep in range(5):
+        t = time.perf_counter()
+        cls = net.L.inference(os.path.join(G, f).encode(), res, 10, C.byref(usec))
+        wall = (time.perf_counter() - t) * 1e6
+        assert cls == want and 0 < usec.value < wall, (network, cls, usec.value, wall)
+    if network == "cnvW1A1":
+        assert list(res[:10]) == [234, 231, 265, 248, 410, 257, 224, 262, 226, 233]
+net = gl.Net("cnvW2A2", "cifar10")
+o = ol.Oracle("cnvW2A2", ol.param_dir("cifar10", "cnvW2A2"))
+img = np.random.default_rng(3).integers(0, 256, (1, 3072), dtype=np.uint8)
+assert (net.raw(img) == o.scores_fast(img)).all()
+print("host-timed-ok")
+""" % (os.path.join(gl.ROOT, "tests"), os.path.join(gl.ROOT, "bnn-pynq_amd"))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BNN_MI355X_DIRECT_TIMING="host"), capture_output=True, text=True, timeout=900)
+    assert "host-timed-ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
 
 
 def test_chunk_override_above_the_workspace_is_cut_on_the_gpu(tmp_path):

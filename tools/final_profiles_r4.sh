@@ -64,6 +64,7 @@ if [ $PART = C ]; then
   BNN_MI355X_NO_HOST_PACK=1 REPS=9 python3 tools/small_call_sweep.py lfcW1A1 10000 default 2>/dev/null | grep -v "^Setting" >> $P
   cat $P
   python3 tools/latency.py 2>&1 | grep -v "^Setting\|amdgpu.ids" > $O/latency.txt
+  BNN_MI355X_DIRECT_TIMING=host python3 tools/latency.py 2>&1 | grep -v "^Setting\|amdgpu.ids" | sed 's/^/BNN_MI355X_DIRECT_TIMING=host (opt-in: no event packets, completion word in pinned memory, usecPerImage by the host clock)  /' >> $O/latency.txt
   BNN_MI355X_NO_DIRECT=1 python3 tools/latency.py 2>&1 | grep -v "^Setting\|amdgpu.ids" | sed 's/^/BNN_MI355X_NO_DIRECT=1 (the round-3 way: copies around the launch)  /' >> $O/latency.txt
   cat $O/latency.txt
   for a in "cnvW1A1 10000" "lfcW1A1 10000" "lfcW1A1 131072"; do python3 tools/call_trace.py $a 2> $O/call_trace_$(echo $a | tr " " _).txt; done
