@@ -1502,10 +1502,14 @@ int infer_any(const Source &src, int n, int ncls, int32_t *classes, int16_t *sco
   if (want_words && !m.d_words && grow_pinned(r.h_words, r.h_words_cap, (size_t)n)) return -1;
   DrainOnFailure drain;
   trace().mark("reserved");
+  // (experiment switch, read per call so that tools/plan_ab.py can interleave it: no timing events around the chunks,
+  // usecPerImage reported as 0 -- what the two marker packets per chunk cost a device-bound call)
+  const bool timed = std::getenv("BNN_MI355X_NO_CHUNK_TIMING") == nullptr;
   auto stages = [&](int c, int base, int mm, int slot) {
     trace().mark("chunk_in", c);
     const int rc = enqueue(r.d_images[slot], mm, ncls, classes ? dc + base : nullptr, want_scores ? ds + (size_t)base * 64 : nullptr, dw + base,
-                           lane_stream(c, lanes), r.time_events[2 * c], r.time_events[2 * c + 1], lanes == 2 ? (c & 1) : 0, nchunks == 1, packed);
+                           lane_stream(c, lanes), timed ? r.time_events[2 * c] : nullptr, timed ? r.time_events[2 * c + 1] : nullptr,
+                           lanes == 2 ? (c & 1) : 0, nchunks == 1, packed);
     trace().mark("queued", c);
     return rc;
   };
@@ -1556,7 +1560,7 @@ int infer_any(const Source &src, int n, int ncls, int32_t *classes, int16_t *sco
   if (words && !r.spec.is_cnv) std::memcpy(words, m.d_words ? m.h_words : r.h_words, (size_t)n * 8);
   if (words_view) *words_view = m.d_words ? m.h_words : r.h_words;
   double total_ms = 0.0;
-  if (chunks_device_ms(nchunks, &total_ms)) return -1;
+  if (timed && chunks_device_ms(nchunks, &total_ms)) return -1;
   if (usec) *usec = (float)(total_ms * 1000.0 / n);
   drain.ok();
   trace().mark("done");

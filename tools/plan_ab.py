@@ -36,10 +36,17 @@ devnull, saved = os.open(os.devnull, os.O_WRONLY), os.dup(1)
 T = {p: {"buffer": [], "file": []} for p in plans}
 
 
+PER_CALL = ("BNN_MI355X_NO_CHUNK_TIMING",)   # switches the library reads at every call: "env:NAME=VALUE" as a plan name
+
+
 def setplan(p):
-    if p == "default":
-        os.environ.pop("BNN_MI355X_CHUNKS", None)
-    else:
+    os.environ.pop("BNN_MI355X_CHUNKS", None)
+    for k in PER_CALL:
+        os.environ.pop(k, None)
+    if p.startswith("env:"):
+        k, v = p[4:].split("=")
+        os.environ[k] = v
+    elif p != "default":
         os.environ["BNN_MI355X_CHUNKS"] = p
 
 
