@@ -1063,7 +1063,8 @@ int feed_chunks(const uint8_t *mem, int fd, size_t first, size_t rec, size_t ski
     HIP_OK(hipEventRecord(r.copied[slot], r.copy_stream));
     HIP_OK(hipStreamWaitEvent(lane_stream(c, lanes), r.copied[slot], 0));
     if (consume(c, base, m, slot)) return -1;
-    HIP_OK(hipEventRecord(r.consumed[slot], lane_stream(c, lanes)));
+    // (only where a later chunk will reuse this buffer: a marker packet on the lane's stream is not free, BNN_MI355X_TRACE)
+    if (c + nslots < nchunks) HIP_OK(hipEventRecord(r.consumed[slot], lane_stream(c, lanes)));
   }
   return 0;
 }
@@ -1255,7 +1256,7 @@ int stream_file(const ImageFile &f, int n, bool reuse_slots, int lanes, Dst dst,
     }
     if (consume(c, base, m, slot)) return -1;
     // (with reuse_slots the consumer's stages read `packed`; without, only the strip kernel reads d_file[slot])
-    if (nchunks > 1) HIP_OK(hipEventRecord(r.consumed[slot], reuse_slots ? lane_stream(c, lanes) : r.copy_stream));
+    if (c + 2 < nchunks) HIP_OK(hipEventRecord(r.consumed[slot], reuse_slots ? lane_stream(c, lanes) : r.copy_stream));
   }
   return 0;
 }
@@ -1543,7 +1544,7 @@ int infer_any(const Source &src, int n, int ncls, int32_t *classes, int16_t *sco
       }
       HIP_OK(hipStreamWaitEvent(lane_stream(c, lanes), r.copied[slot], 0));
       if (stages(c, base, mm, slot)) return -1;
-      HIP_OK(hipEventRecord(r.consumed[slot], lane_stream(c, lanes)));
+      if (c + nslots < nchunks) HIP_OK(hipEventRecord(r.consumed[slot], lane_stream(c, lanes)));  // (a later chunk reuses the slot)
       if (!one_thread) K.consumed.store(c + 1, std::memory_order_release);
     }
   }
