@@ -36,7 +36,7 @@ devnull, saved = os.open(os.devnull, os.O_WRONLY), os.dup(1)
 T = {p: {"buffer": [], "file": []} for p in plans}
 
 
-PER_CALL = ("BNN_MI355X_NO_CHUNK_TIMING",)   # switches the library reads at every call: "env:NAME=VALUE" as a plan name
+PER_CALL = ("BNN_MI355X_NO_CHUNK_TIMING", "BNN_MI355X_LANES", "BNN_MI355X_STAGE_SLOTS", "BNN_MI355X_NO_CALLER_HEAD", "BNN_MI355X_FEEDER_FLUSH")   # switches the library reads at every call: "env:NAME=VALUE" as a plan name
 
 
 def setplan(p):
@@ -51,6 +51,7 @@ def setplan(p):
 
 
 usec, cnt = C.c_float(0), C.c_int(0)
+want = None
 os.dup2(devnull, 1)
 for r in range(rounds + 2):
     for p in (plans if r % 2 == 0 else plans[::-1]):
@@ -58,11 +59,16 @@ for r in range(rounds + 2):
         t = time.perf_counter()
         q = L.bnn_mi355x_inference_buffer(imgs.ctypes.data, n, 10, C.byref(usec), 0)
         tb = time.perf_counter() - t
+        got = np.ctypeslib.as_array(q, (n,)).copy()
         L.free_results(q)
         t = time.perf_counter()
         q = L.inference_multiple(f.name.encode(), 10, C.byref(cnt), C.byref(usec), 0)
         tf = time.perf_counter() - t
+        got2 = np.ctypeslib.as_array(q, (n,)).copy()
         L.free_results(q)
+        if want is None:
+            want = got
+        assert (got == want).all() and (got2 == want).all(), "classes differ under plan " + p
         if r >= 2:
             T[p]["buffer"].append(tb)
             T[p]["file"].append(tf)
