@@ -61,7 +61,7 @@ namespace {
 
 constexpr int kMaxChunk = 131072;  // images per pass through the stages
 constexpr int kForkMin = 16384;     // images: a device-pointer pass of a CNV net of this size and more forks over the two compute lanes
-constexpr int kStageSlots = 6;      // HBM staging buffers of the host paths: two per compute lane (one lane 2, two lanes 4, the three-lane experiment 6)
+constexpr int kStageSlots = 4;      // HBM staging buffers of the host paths: two on one compute lane, four on two
 // Events that only TIME device work: a device-scope release at the record point instead of a flush to system scope
 // ("useful to obtain more precise timings of commands between events", hip_runtime_api.h).  Nothing on the host reads
 // results on the strength of these events: every entry point fetches them with a copy + stream synchronisation.
@@ -191,11 +191,6 @@ struct Runtime {
   void *buf0b = nullptr, *buf1b = nullptr;
   hipStream_t stream2 = nullptr;
   hipEvent_t lane2_done = nullptr;
-  // third lane (CNV calls of four or more chunks, lanes_for)
-  int cap3 = 0;
-  void *buf0c = nullptr, *buf1c = nullptr;
-  hipStream_t stream3 = nullptr;
-  hipEvent_t lane3_done = nullptr;
   // host-buffer path: two image staging buffers in HBM (ping-pong) + results for the whole call
   int stage_cap = 0;
   // (kStageSlots buffers exist once a call has run on two lanes: each lane consumes one while the next chunk of each arrives)
@@ -224,7 +219,7 @@ struct Runtime {
   bool ws_pending = false;
   // (both workspaces since such a call may fork over the two lanes: the library's own two streams each remember the last
   // hand-over they have waited for, a caller's stream waits whenever one is pending)
-  uint64_t ws_gen = 0, ws_seen[3] = {0, 0, 0};
+  uint64_t ws_gen = 0, ws_seen[2] = {0, 0};
   hipEvent_t fork_ev = nullptr;
   hipEvent_t copied[kStageSlots] = {}, consumed[kStageSlots] = {};
   std::vector<hipEvent_t> time_events;
@@ -304,12 +299,15 @@ int bind_device() {
   if (r.device >= 0) HIP_OK(hipSetDevice(r.device));
   else HIP_OK(hipGetDevice(&r.device));  // first use: the calling thread's current device is this library's from now on
   if (!r.stream) {
+    // Four streams in all with the feeder's second DMA queue (Feeder::aux) -- and no more: the runtime maps a process's
+    // streams onto four hardware queues, a fifth stream shares one with an earlier stream and the two then serialise.
+    // Found the hard way in round 4: a third compute lane (its stream created here) put Feeder::aux on this stream's
+    // queue and cost the file path 20 % (131 072 records 11.3 -> 13.6 ms) before a single chunk ran on it
+    // (profiles/r04_third_lane_experiment.txt).
     HIP_OK(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&r.copy_stream, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&r.stream2, hipStreamNonBlocking));
     HIP_OK(hipEventCreateWithFlags(&r.lane2_done, hipEventDisableTiming));
-    HIP_OK(hipStreamCreateWithFlags(&r.stream3, hipStreamNonBlocking));
-    HIP_OK(hipEventCreateWithFlags(&r.lane3_done, hipEventDisableTiming));
     for (int i = 0; i < kStageSlots; i++) {
       HIP_OK(hipEventCreateWithFlags(&r.copied[i], hipEventDisableTiming));
       HIP_OK(hipEventCreateWithFlags(&r.consumed[i], hipEventDisableTiming));
@@ -332,7 +330,6 @@ struct DrainOnFailure {
     Runtime &r = rt();
     if (r.stream) (void)hipStreamSynchronize(r.stream);
     if (r.stream2) (void)hipStreamSynchronize(r.stream2);
-    if (r.stream3) (void)hipStreamSynchronize(r.stream3);
     if (r.copy_stream) (void)hipStreamSynchronize(r.copy_stream);
     drain_feeder();  // DMAs still reading the pinned ring: the next job's workers would refill it under them
   }
@@ -392,9 +389,6 @@ void free_workspace() {
   (void)hipFree(r.buf0b); (void)hipFree(r.buf1b);
   r.buf0b = r.buf1b = nullptr;
   r.cap2 = 0;
-  (void)hipFree(r.buf0c); (void)hipFree(r.buf1c);
-  r.buf0c = r.buf1c = nullptr;
-  r.cap3 = 0;
   (void)hipFree(r.d_all);
   r.d_all = nullptr;
   r.all_cap = 0;
@@ -468,35 +462,10 @@ int reserve(int n) {
 // images 87.7 -> 100.7 ms); with four: 131 072 images from a host buffer 11.55 -> 11.3 ms, from a file 12.6-13.3 ->
 // 11.7-12.0 ms, 524 288 from a file 46.1-48.3 -> 44.6-44.9 ms (profiles/r03_two_lanes_ab.txt).
 // BNN_MI355X_LANES=1 forces one lane (A/B); stage profiling and the stage-output hook always run on one lane.
-// A THIRD lane for CNV calls of four or more chunks (round 4, interleaved A/B, profiles/r04_plan_ab_interleaved.txt): a
-// 10 000-record file 1.449 -> 1.335 ms, 131 072 records 14.8 -> 13.6 ms on a box whose file path was the slow one, cnvW2A2
-// 10 000 records 2.50 -> 2.35 ms; host buffers within 1 % either way, the LFC nets (one launch per chunk) unchanged: they
-// stay on two.  Six staging buffers alone (two lanes) gave a third of that.  BNN_MI355X_LANES=1 / 2 / 3 forces the count
-// (read per call, so that tools/plan_ab.py can interleave it); the device-pointer fork stays at two lanes.
 int lanes_for(int nchunks) {
-  const char *e = std::getenv("BNN_MI355X_LANES");
+  static const bool one = [] { const char *e = std::getenv("BNN_MI355X_LANES"); return e && std::atoi(e) == 1; }();
   const Runtime &r = rt();
-  const int want = e ? std::atoi(e) : (r.spec.is_cnv ? 3 : 2);
-  if (nchunks < 3 || want == 1 || r.profiling || r.debug_last_stage >= 0) return 1;
-  return (want >= 3 && nchunks >= 4) ? 3 : 2;
-}
-// the third lane's activation workspace
-int reserve3(int n) {
-  Runtime &r = rt();
-  if (n > kMaxChunk) n = kMaxChunk;
-  if (n <= r.cap3) return 0;
-  if (bind_device()) return -1;
-  HIP_OK(hipDeviceSynchronize());
-  (void)hipFree(r.buf0c); (void)hipFree(r.buf1c);
-  r.buf0c = r.buf1c = nullptr;
-  r.cap3 = 0;
-  size_t b0, b1;
-  if (r.spec.is_cnv) cnv_workspace_bytes(r.spec.abits, &b0, &b1);
-  else lfc_workspace_bytes(r.spec.abits, &b0, &b1);
-  HIP_OK(hipMalloc(&r.buf0c, (size_t)n * b0 + 256));
-  HIP_OK(hipMalloc(&r.buf1c, (size_t)n * b1 + 256));
-  r.cap3 = n;
-  return 0;
+  return (nchunks >= 3 && !one && !r.profiling && r.debug_last_stage < 0) ? 2 : 1;
 }
 // the second lane's activation workspace for `n` images per pass
 int reserve2(int n) {
@@ -518,30 +487,15 @@ int reserve2(int n) {
 }
 // HBM staging buffers of a call on `lanes` lanes: chunk c lands in slot c % slots and runs on lane c & 1 -- with two
 // buffers both would be held by the two chunks in flight and the next copy could not start before one of them ends
-int slots_for(int lanes) {
-  if (lanes > 1)
-    if (const char *e = std::getenv("BNN_MI355X_STAGE_SLOTS")) {  // experiment (read per call): more staging buffers than two per lane
-      const int v = std::atoi(e);
-      if (v >= 2 * lanes && v <= kStageSlots) return v;
-    }
-  return 2 * lanes;
-}
+int slots_for(int lanes) { return lanes == 2 ? kStageSlots : 2; }
 // chunk c of a call that runs on `lanes` lanes: its stream
-int lane_of(int c, int lanes) { return lanes > 1 ? c % lanes : 0; }
-hipStream_t lane_stream(int c, int lanes) {
-  const int l = lane_of(c, lanes);
-  return l == 0 ? rt().stream : (l == 1 ? rt().stream2 : rt().stream3);
-}
+hipStream_t lane_stream(int c, int lanes) { return (lanes == 2 && (c & 1)) ? rt().stream2 : rt().stream; }
 // all chunks are enqueued: whatever follows on r.stream (the results' way back) comes behind the second lane too
 int join_lanes(int lanes) {
   Runtime &r = rt();
-  if (lanes >= 2) {
+  if (lanes == 2) {
     HIP_OK(hipEventRecord(r.lane2_done, r.stream2));
     HIP_OK(hipStreamWaitEvent(r.stream, r.lane2_done, 0));
-  }
-  if (lanes == 3) {
-    HIP_OK(hipEventRecord(r.lane3_done, r.stream3));
-    HIP_OK(hipStreamWaitEvent(r.stream, r.lane3_done, 0));
   }
   return 0;
 }
@@ -654,7 +608,7 @@ ResultSlots mapped_results(int n, bool scores, bool direct = false) {
 // `s` waits for its end first.
 int settle_handover(hipStream_t s) {
   Runtime &r = rt();
-  const int own = s == r.stream ? 0 : (s == r.stream2 ? 1 : (s == r.stream3 ? 2 : -1));
+  const int own = s == r.stream ? 0 : (s == r.stream2 ? 1 : -1);
   if (own >= 0 ? (r.ws_seen[own] == r.ws_gen || r.ws_last == s) : (!r.ws_pending || r.ws_last == s)) return 0;
   {
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -688,9 +642,9 @@ int enqueue(const uint8_t *d_imgs, int n, int ncls, int32_t *d_classes, int16_t 
   Runtime &r = rt();
   hipError_t e;
   hipEvent_t *evs = nullptr;
-  void *const ws0 = lane == 2 ? r.buf0c : (lane ? r.buf0b : r.buf0), *const ws1 = lane == 2 ? r.buf1c : (lane ? r.buf1b : r.buf1);
+  void *const ws0 = lane ? r.buf0b : r.buf0, *const ws1 = lane ? r.buf1b : r.buf1;
   // (the stages index the workspace by image: a chunk above its capacity would write past it on the device)
-  if (n > (lane == 2 ? r.cap3 : (lane ? r.cap2 : r.cap))) return fail("internal: a chunk of " + std::to_string(n) + " images exceeds the activation workspace");
+  if (n > (lane ? r.cap2 : r.cap)) return fail("internal: a chunk of " + std::to_string(n) + " images exceeds the activation workspace");
   if (settle_handover(s)) return -1;
   if (r.profiling) {
     const int need = (r.spec.is_cnv ? kCnvStages : kLfcStages) + 1;
@@ -818,7 +772,6 @@ struct Feeder {
   size_t filled_cap = 0;
   std::atomic<bool> abort{false};
   int active = 0;  // workers that have not yet left the current job (under mu)
-  std::atomic<int> workers_in{0};  // workers that have started on the current job
   // BNN_MI355X_TRACE: per worker, microseconds from begin() to its first claim, microseconds spent filling, pieces filled
   struct Stat { double first = -1, busy = 0; int pieces = 0; };
   Stat stats[kMaxWorkers + 1];
@@ -921,7 +874,6 @@ struct Feeder {
         seen = job_id;
         if (index >= job_workers) continue;  // not needed for this job (and not counted in `active`)
       }
-      workers_in.fetch_add(1, std::memory_order_release);
       while (work_one(index)) {}
       std::lock_guard<std::mutex> lk(mu);
       if (--active == 0) cv_done.notify_all();
@@ -968,7 +920,7 @@ struct Feeder {
       filled_cap = pcs.size();
     }
     for (size_t i = 0; i < pcs.size(); i++) filled[i].store(0, std::memory_order_relaxed);
-    next = 0; released = 0; abort = false; workers_in = 0;
+    next = 0; released = 0; abort = false;
     if (trace().on) {
       for (auto &st : stats) st = Stat{};
       job_t0 = std::chrono::steady_clock::now();
@@ -976,9 +928,6 @@ struct Feeder {
     {
       std::lock_guard<std::mutex> lk(mu);
       pieces = &pcs; mem = m; fd = f; packed = pack; rec = item_bytes; skip = drop;
-#if defined(__x86_64__)
-      if (const char *e = std::getenv("BNN_MI355X_FEEDER_FLUSH")) flush = std::atoi(e) != 0 && __builtin_cpu_supports("clflushopt");  // (per call: A/B)
-#endif
       const int want = pack ? (int)workers.size() : raw_workers;
       // (no more threads than pieces: a thread woken for nothing still has to be waited for at the end)
       job_workers = (size_t)want < pcs.size() ? want : (int)pcs.size();
@@ -986,16 +935,7 @@ struct Feeder {
       job_id++;
       cv_job.notify_all();
     }
-    // The first piece by this thread, while the workers wake up -- and, as long as none of them has shown up, the rest of
-    // the first group as well: the calling thread is the one core that is certainly awake.  (On the boxes of round 4 the
-    // workers claim their first piece 20-45 us after the wake-up even after a pause, and the interleaved A/B with
-    // BNN_MI355X_NO_CALLER_HEAD shows no difference: a guard against slower wake-ups, not a gain.)
-    (void)work_one();
-    if (std::getenv("BNN_MI355X_NO_CALLER_HEAD") == nullptr) {
-      size_t head = 0;
-      while (head < pcs.size() && pcs[head].group == 0) head++;
-      while (workers_in.load(std::memory_order_acquire) == 0 && next.load(std::memory_order_relaxed) < head && work_one()) {}
-    }
+    (void)work_one();  // the first piece by this thread, while the workers wake up
   }
   // every worker has left the job: its description may go out of scope
   void end() {
@@ -1550,7 +1490,7 @@ int infer_any(const Source &src, int n, int ncls, int32_t *classes, int16_t *sco
   const bool ring = packed || ((from_file || feed_host) && nchunks > 1 && use_feeder((size_t)n * rec) && feeder().init() == 0);
   const int lanes = lanes_for(nchunks);
   const int nslots = slots_for(lanes);
-  if (reserve(chunk) || (lanes >= 2 && reserve2(chunk)) || (lanes == 3 && reserve3(chunk)) || reserve_host(chunk, (size_t)n, nslots)) return -1;
+  if (reserve(chunk) || (lanes == 2 && reserve2(chunk)) || reserve_host(chunk, (size_t)n, nslots)) return -1;
   while ((int)r.time_events.size() < 2 * nchunks) {
     hipEvent_t e;
     HIP_OK(hipEventCreateWithFlags(&e, kTimeEventFlags));
@@ -1575,7 +1515,7 @@ int infer_any(const Source &src, int n, int ncls, int32_t *classes, int16_t *sco
     trace().mark("chunk_in", c);
     const int rc = enqueue(r.d_images[slot], mm, ncls, classes ? dc + base : nullptr, want_scores ? ds + (size_t)base * 64 : nullptr, dw + base,
                            lane_stream(c, lanes), timed ? r.time_events[2 * c] : nullptr, timed ? r.time_events[2 * c + 1] : nullptr,
-                           lane_of(c, lanes), nchunks == 1, packed);
+                           lanes == 2 ? (c & 1) : 0, nchunks == 1, packed);
     trace().mark("queued", c);
     return rc;
   };

@@ -165,9 +165,8 @@ int bnn_mi355x_reserve(int max_images);
  *    images ramps down again at its end (512 last).  A file is read by worker threads straight into a ring of pinned pieces, the label
  *    byte of every record dropped on the way (preadv); a host buffer goes through the runtime's pageable path, its copies
  *    issued by a helper thread while the calling thread enqueues stages.
- * A call of three or more chunks runs them alternately on two internal streams ("compute lanes"; a CNV call of four or more
- * chunks: three), each with its own activation workspace; usecPerImage is then the union of the chunks' device intervals over
- * the images.  Results of calls up to 32 768
+ * A call of three or more chunks runs them alternately on two internal streams ("compute lanes"), each with its own activation
+ * workspace; usecPerImage is then the union of the chunks' device intervals over the images.  Results of calls up to 32 768
  * images are written by the last stage into pinned memory, larger ones come back in one transfer at the end.
  * chunk_plan writes the chunk boundaries base[0] = 0 < base[1] < ... < base[k] = n (at most cap of them) and returns k + 1
  * (from_file is accepted for compatibility: both entry points use the same plan since round 4).  Host only; results never

@@ -36,7 +36,7 @@ devnull, saved = os.open(os.devnull, os.O_WRONLY), os.dup(1)
 T = {p: {"buffer": [], "file": []} for p in plans}
 
 
-PER_CALL = ("BNN_MI355X_NO_CHUNK_TIMING", "BNN_MI355X_LANES", "BNN_MI355X_STAGE_SLOTS", "BNN_MI355X_NO_CALLER_HEAD", "BNN_MI355X_FEEDER_FLUSH")   # switches the library reads at every call: "env:NAME=VALUE" as a plan name
+PER_CALL = ("BNN_MI355X_NO_CHUNK_TIMING",)   # switches the library reads at every call: "env:NAME=VALUE" as a plan name
 
 
 def setplan(p):
