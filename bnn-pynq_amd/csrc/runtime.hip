@@ -1397,7 +1397,7 @@ int infer_direct(const Source &src, int n, int ncls, int32_t *classes, int16_t *
   // BNN_MI355X_DIRECT_TIMING=host (opt-in, one image): the call is timed and waited for WITHOUT the runtime -- no event
   // packets around the launch, the last kernel stores a completion word into the pinned block behind its results, the host
   // spins on that word, and usecPerImage is the host's clock from the launch to the word, i.e. the reference's own
-  // definition (wall clock around the accelerator call, foldedmv-offload.cpp:140-143) instead of this runtime's (device
+  // definition (wall clock around the accelerator call, foldedmv-offload.cpp:138-140, foldedmv-offload.h:342-345) instead of this runtime's (device
   // time by events).  tools/launch_latency_probe.hip, profiles/r04_launch_latency_probe.txt: the two timing events cost
   // 4.3 us in the launch call and ~2 us in a later kernel start, the event's readiness is seen ~2 us after the word:
   // 21.5 -> 13.9 us around an 8 us kernel.  The default keeps the events: usecPerImage keeps its meaning.
