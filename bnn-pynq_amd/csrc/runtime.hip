@@ -191,6 +191,7 @@ struct Runtime {
   void *buf0b = nullptr, *buf1b = nullptr;
   hipStream_t stream2 = nullptr;
   hipEvent_t lane2_done = nullptr;
+  hipStream_t feed_aux = nullptr;  // the pinned ring's second DMA queue (Feeder::aux), created with the streams above
   // host-buffer path: two image staging buffers in HBM (ping-pong) + results for the whole call
   int stage_cap = 0;
   // (kStageSlots buffers exist once a call has run on two lanes: each lane consumes one while the next chunk of each arrives)
@@ -307,6 +308,13 @@ int bind_device() {
     HIP_OK(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&r.copy_stream, hipStreamNonBlocking));
     HIP_OK(hipStreamCreateWithFlags(&r.stream2, hipStreamNonBlocking));
+    // (the feeder's second DMA queue is created HERE, right behind the other three, although the feeder itself comes into
+    // being only with the first call that needs it: streams the application creates in between would otherwise decide
+    // which of this library's streams it shares a hardware queue with.  BNN_MI355X_FEEDER_STREAMS=1: one DMA queue.)
+    {
+      const char *es = std::getenv("BNN_MI355X_FEEDER_STREAMS");
+      if (!es || std::atoi(es) == 2) HIP_OK(hipStreamCreateWithFlags(&r.feed_aux, hipStreamNonBlocking));
+    }
     HIP_OK(hipEventCreateWithFlags(&r.lane2_done, hipEventDisableTiming));
     for (int i = 0; i < kStageSlots; i++) {
       HIP_OK(hipEventCreateWithFlags(&r.copied[i], hipEventDisableTiming));
@@ -890,11 +898,9 @@ struct Feeder {
     if (hipHostMalloc(reinterpret_cast<void **>(&ring), kSlots * kSlotBytes, hipHostMallocDefault) != hipSuccess) { ring = nullptr; return -1; }
     for (auto &e : sent)
       if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return -1;
-    const char *es = std::getenv("BNN_MI355X_FEEDER_STREAMS"), *ef = std::getenv("BNN_MI355X_FEEDER_FLUSH");
-    if (!es || std::atoi(es) == 2) {
-      if (hipStreamCreateWithFlags(&aux, hipStreamNonBlocking) != hipSuccess) return -1;
-      if (hipEventCreateWithFlags(&aux_done, hipEventDisableTiming) != hipSuccess) return -1;
-    }
+    const char *ef = std::getenv("BNN_MI355X_FEEDER_FLUSH");
+    aux = rt().feed_aux;  // (created in bind_device, next to the library's other streams: see there)
+    if (aux && hipEventCreateWithFlags(&aux_done, hipEventDisableTiming) != hipSuccess) return -1;
 #if defined(__x86_64__)
     flush = (ef ? std::atoi(ef) != 0 : false) && __builtin_cpu_supports("clflushopt");
 #endif
