@@ -17,7 +17,10 @@ edges = {"cnv": [1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1023, 
                  16383, 16384, 16385, 16641],             # the device call forks over two lanes from 16 384 images
          "lfc": [1, 2, 63, 65, 255, 257, 511, 513, 1023, 1025, 2047, 2048, 2049, 4095, 4096, 4097, 6000, 8191, 12289, 20001,
                  32767, 32768, 32769, 33000]}
+nets_filter = os.environ.get("NETS")  # e.g. NETS=lfcW1A1,lfcW1A2: the "sizes" section for those networks only
 for net, ds in (("cnvW1A1", "cifar10"), ("cnvW1A2", "cifar10"), ("cnvW2A2", "cifar10"), ("lfcW1A1", "mnist"), ("lfcW1A2", "mnist")) if only in ("all", "sizes") else ():
+    if nets_filter and net not in nets_filter.split(","):
+        continue
     N = gl.Net(net, ds)
     o = ol.Oracle(net, ol.param_dir(ds, net))
     kind = net[:3]
