@@ -1022,6 +1022,10 @@ int feed_chunks(const uint8_t *mem, int fd, size_t first, size_t rec, size_t ski
         pc.last_of_chunk = pc.last_of_group && g0 + gi == items;
         pc.group_dst_off = g0 * out;
         pc.group_bytes = gi * out;
+        // (what the ring and the HBM buffers rely on, checked where it is decided: a piece ends inside its group's ring slot,
+        // a group inside its chunk's buffer)
+        if (pc.ring_off + b * out > F.kSlotBytes || pc.group_bytes > F.kSlotBytes || pc.group_dst_off + pc.group_bytes > items * out)
+          return fail("internal: feed plan outside the ring slot / chunk buffer");
         pieces.push_back(pc);
         o += b;
       }
