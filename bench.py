@@ -400,7 +400,7 @@ def measure_config(network, dataset, batch, dev, device_index, steps, warmup, ch
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)   # (1 s of timed device work at the default batch: long enough for a coarse GPU-busy sampler to see it)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=131072, help="images per GPU per step")
     ap.add_argument("--network", default="cnvW1A1")
