@@ -74,13 +74,15 @@ constexpr int kFastGrowthBelow = 4096;  // ... chunks double up to here, then gr
 // no hipMemcpy, no staging, one wait.  Input area: a single CIFAR record (body 16-byte aligned) or up to kDirectMaxLfc
 // host-binarised MNIST images; result area: classes / raw words of up to kMappedResMax images, scores of kMappedScoresMax.
 constexpr int kDirectMaxLfc = 1024;   // images: an LFC call up to here is binarised by the calling thread and read in place
-constexpr int kDirectMaxCnv = 1;      // a single CIFAR image (classify_image / the webcam loop: inference(path) per frame)
+constexpr int kDirectMaxCnv = 32;     // CIFAR images from a host buffer (classify_image(s) of a few pictures: whole call 38-46 us against 46-59 through a copy,
+                                      // profiles/r04_small_n_latency.txt; beyond ~64 the kernels' reads over the link cost more than the copy); from a FILE: one
 constexpr int kMappedResMax = 32768, kMappedScoresMax = 256;
 constexpr size_t kIoInBytes = 256u << 10;
 constexpr size_t kIoClassesOff = kIoInBytes, kIoWordsOff = kIoClassesOff + (size_t)kMappedResMax * 4,
                  kIoScoresOff = kIoWordsOff + (size_t)kMappedResMax * 8, kIoDoneOff = kIoScoresOff + (size_t)kMappedScoresMax * 128,
                  kIoBytes = kIoDoneOff + 64;  // (the last 64 bytes: the completion word of single-image calls timed by the host)
-static_assert((size_t)kDirectMaxLfc * kLfcWords * 8 <= kIoInBytes && 16 + 3073 <= kIoInBytes, "input area too small");
+static_assert((size_t)kDirectMaxLfc * kLfcWords * 8 <= kIoInBytes && 16 + 3073 <= kIoInBytes && 16 + (size_t)kDirectMaxCnv * 3072 <= kIoInBytes,
+              "input area too small");
 
 // Chunk boundaries of a host-buffer / file call: base[c] .. base[c+1] are the images of chunk c.
 // The pipeline is copy | stages, double buffered per compute lane.  With equal chunks the first copy (32 768 CIFAR records
@@ -1380,10 +1382,10 @@ int infer_direct(const Source &src, int n, int ncls, int32_t *classes, int16_t *
   const uint8_t *d_in = r.d_io;
   if (r.spec.is_cnv) {
     // the kernels read an image with 128-bit loads: the body (3072 bytes behind the label byte) starts at +16
-    if (src.file) {
+    if (src.file) {  // (n == 1: the records of a file are a label byte apart)
       if (::pread(src.file->fd, r.h_io + 15, 3073, (off_t)src.file->first) != 3073) return fail("input file: read error");
     } else {
-      std::memcpy(r.h_io + 16, src.mem, 3072);
+      std::memcpy(r.h_io + 16, src.mem, (size_t)n * 3072);
     }
     d_in = r.d_io + 16;
   } else if (src.file) {
@@ -1478,7 +1480,7 @@ int infer_any(const Source &src, int n, int ncls, int32_t *classes, int16_t *sco
   const bool hook = r.debug_last_stage >= 0;  // (the stage-output test hook reads the workspace after the call: all images in it, one chunk, device binarisation)
   const bool want_scores = scores && r.spec.is_cnv;
   static const bool no_direct = std::getenv("BNN_MI355X_NO_DIRECT") != nullptr;  // A/B
-  if (!hook && !r.profiling && !no_direct && n <= (r.spec.is_cnv ? kDirectMaxCnv : kDirectMaxLfc) && (!want_scores || n <= kMappedScoresMax))
+  if (!hook && !r.profiling && !no_direct && n <= (r.spec.is_cnv ? (from_file ? 1 : kDirectMaxCnv) : kDirectMaxLfc) && (!want_scores || n <= kMappedScoresMax))
     return infer_direct(src, n, ncls, classes, scores, words, usec, words_view);
   const size_t isz = (size_t)r.spec.image_bytes();
   const size_t rec = from_file ? src.file->rec : isz, skip = from_file ? src.file->skip : 0, first = from_file ? src.file->first : 0;

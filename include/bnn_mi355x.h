@@ -155,7 +155,7 @@ int bnn_mi355x_inference_device(const void *d_images, int n_images, int number_c
 int bnn_mi355x_reserve(int max_images);
 
 /* How the entry points that take HOST data (inference_multiple, inference_buffer, inference_raw) move it:
- *  - a single CIFAR image, or up to 1 024 MNIST images: no transfer at all -- the image (LFC: binarised by the calling thread)
+ *  - a single CIFAR image from a file, up to 32 from a host buffer, or up to 1 024 MNIST images: no transfer at all -- the image (LFC: binarised by the calling thread)
  *    is placed in pinned memory the GPU addresses, the one-launch kernels read it over the link and write their results into
  *    pinned memory; one launch, one wait.
  *  - the LFC networks otherwise: worker threads binarise (bnn_mi355x_binarize_pack) into pinned memory, 104 bytes per image

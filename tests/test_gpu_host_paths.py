@@ -204,3 +204,18 @@ def test_file_records_with_every_label_byte(tmp_path):
         write_file(path, imgs, True, labels=(np.arange(n) % 256).astype(np.uint8))
         det, _ = classify_file(net.L, path, n, detail=1)
         assert (det.reshape(n, 10) == net.raw(imgs)[:, :10]).all(), n
+
+
+@pytest.mark.parametrize("network", ["cnvW1A1", "cnvW1A2", "cnvW2A2"])
+def test_a_few_cifar_images_from_a_host_buffer_are_read_in_place(network):
+    """up to 32 CIFAR images handed over in host memory take the direct way (copied into the pinned I/O block, read there by the
+    kernels, scores / classes written back into it): raw scores, batched classes and detail scores either side of the limit,
+    against the restatement; repeated calls (the block is reused)"""
+    net, o = gpu_net(network, "cifar10"), oracle(network, "cifar10")
+    for n in (2, 3, 7, 31, 32, 33):
+        imgs = rand_images(network, n, 70 + n, "edges" if n % 2 else "uniform")
+        want = o.scores_fast(imgs)
+        for rep in range(2):
+            assert (net.raw(imgs) == want).all(), (network, n)
+        assert (net.classify(imgs, 10) == o.classes_batched(imgs, 10)).all(), (network, n)
+        assert (net.classify(imgs, 10, detail=True).reshape(n, 10) == want[:, :10]).all(), (network, n)
